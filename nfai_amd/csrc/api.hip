@@ -1,0 +1,647 @@
+// api.hip — C ABI of libnfai_hip.so: context, buffers (the HipBufferManager side of
+// VulkanBufferManager) and the 1:1 / fused operator entry points.  See include/nfai_hip.h for the
+// reference member each function replaces.
+#include <stdarg.h>
+#include <string.h>
+
+#include <mutex>
+#include <unordered_set>
+
+#include "common.h"
+
+namespace nfai {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+// Handles are pointers, but they are only dereferenced after a lookup in the table of live
+// objects: a stale or made-up handle is an error status, never a wild read.
+static std::mutex g_handles_mu;
+static std::unordered_set<uint64_t> g_handles;
+
+void handle_register(const void *p)
+{
+    std::lock_guard<std::mutex> lk(g_handles_mu);
+    g_handles.insert(reinterpret_cast<uint64_t>(p));
+}
+void handle_unregister(const void *p)
+{
+    std::lock_guard<std::mutex> lk(g_handles_mu);
+    g_handles.erase(reinterpret_cast<uint64_t>(p));
+}
+bool handle_live(uint64_t h)
+{
+    std::lock_guard<std::mutex> lk(g_handles_mu);
+    return g_handles.count(h) != 0;
+}
+
+Ctx *ctx_of(nfai_ctx_t h)
+{
+    if (!handle_live(h)) return nullptr;
+    Ctx *c = reinterpret_cast<Ctx *>(h);
+    return c->magic == 0x4E464358 ? c : nullptr;
+}
+
+Buf *buf_of(nfai_buf_t h)
+{
+    if (!handle_live(h)) return nullptr;
+    Buf *b = reinterpret_cast<Buf *>(h);
+    return b->magic == 0x4E464246 ? b : nullptr;
+}
+
+uint64_t weight_row_bytes(int t, uint64_t n_cols)
+{
+    switch (t) {
+        case NFAI_F32: return n_cols * 4;
+        case NFAI_F16: return n_cols % 8 == 0 ? n_cols * 2 : 0;
+        case NFAI_Q4_K: return n_cols % 256 == 0 ? n_cols / 256 * 144 : 0;
+        case NFAI_Q6_K: return n_cols % 256 == 0 ? n_cols / 256 * 210 : 0;
+    }
+    return 0;
+}
+
+}  // namespace nfai
+
+using namespace nfai;
+
+#define CTX_OR_FAIL(c, h)                                                    \
+    Ctx *c = ctx_of(h);                                                      \
+    if (!c) return fail(NFAI_ERR_INVALID, "%s: invalid context handle", __func__); \
+    HIP_TRY(hipSetDevice(c->device))
+
+#define BUF_OR_FAIL(b, h)                                                   \
+    Buf *b = buf_of(h);                                                     \
+    if (!b) return fail(NFAI_ERR_INVALID, "%s: invalid buffer handle (%s)", __func__, #h)
+
+#define LAUNCH_TRY(expr)                                                                        \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return fail(_e == hipErrorInvalidValue ? NFAI_ERR_INVALID : NFAI_ERR_HIP,           \
+                        "%s: launch failed: %s", __func__, hipGetErrorString(_e));              \
+    } while (0)
+
+NFAI_API const char *nfai_hip_last_error(void) { return g_last_error.c_str(); }
+NFAI_API int32_t nfai_hip_abi_version(void) { return NFAI_HIP_ABI_VERSION; }
+
+// ---- context ---------------------------------------------------------------------------------
+static int ctx_create_impl(int device, void *stream, bool own, nfai_ctx_t *out)
+{
+    if (!out) return fail(NFAI_ERR_INVALID, "ctx_create: out is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(NFAI_ERR_HIP, "ctx_create: no HIP device visible (%s) — this backend has no CPU fallback",
+                    hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(NFAI_ERR_INVALID, "ctx_create: device %d out of range [0,%d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    Ctx *c = new Ctx();
+    c->device = device;
+    HIP_TRY(hipGetDeviceProperties(&c->prop, device));
+    if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+        const std::string arch = c->prop.gcnArchName;
+        delete c;
+        return fail(NFAI_ERR_UNSUPPORTED, "ctx_create: device arch %s is not gfx950 (kernels are built for MI355X only)",
+                    arch.c_str());
+    }
+    if (own) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    } else {
+        c->stream = reinterpret_cast<hipStream_t>(stream);
+    }
+    c->owns_stream = own;
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    c->scratch_bytes = 1 << 20;
+    HIP_TRY(hipMalloc(&c->scratch, c->scratch_bytes));
+    HIP_TRY(hipMemset(c->scratch, 0, c->scratch_bytes));
+    handle_register(c);
+    *out = reinterpret_cast<nfai_ctx_t>(c);
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_ctx_create(int32_t device, nfai_ctx_t *out) { return ctx_create_impl(device, nullptr, true, out); }
+NFAI_API int32_t nfai_hip_ctx_create_on_stream(int32_t device, void *stream, nfai_ctx_t *out)
+{
+    return ctx_create_impl(device, stream, false, out);
+}
+
+NFAI_API int32_t nfai_hip_ctx_destroy(nfai_ctx_t h)
+{
+    CTX_OR_FAIL(c, h);
+    hipStreamSynchronize(c->stream);
+    hipEventDestroy(c->ev0);
+    hipEventDestroy(c->ev1);
+    hipFree(c->scratch);
+    if (c->owns_stream) hipStreamDestroy(c->stream);
+    c->magic = 0;
+    handle_unregister(c);
+    delete c;
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_ctx_synchronize(nfai_ctx_t h)
+{
+    CTX_OR_FAIL(c, h);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_ctx_device_info(nfai_ctx_t h, nfai_device_info *info)
+{
+    CTX_OR_FAIL(c, h);
+    if (!info) return fail(NFAI_ERR_INVALID, "device_info: info is null");
+    memset(info, 0, sizeof(*info));
+    strncpy(info->name, c->prop.name, sizeof(info->name) - 1);
+    strncpy(info->arch, c->prop.gcnArchName, sizeof(info->arch) - 1);
+    info->total_mem_bytes = c->prop.totalGlobalMem;
+    info->compute_units = (uint32_t)c->prop.multiProcessorCount;
+    info->wavefront_size = (uint32_t)c->prop.warpSize;
+    info->lds_bytes_per_cu = (uint32_t)c->prop.maxSharedMemoryPerMultiProcessor;
+    info->clock_khz = (uint32_t)c->prop.clockRate;
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_timer_begin(nfai_ctx_t h)
+{
+    CTX_OR_FAIL(c, h);
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_timer_end(nfai_ctx_t h, float *ms)
+{
+    CTX_OR_FAIL(c, h);
+    if (!ms) return fail(NFAI_ERR_INVALID, "timer_end: ms is null");
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return NFAI_OK;
+}
+
+// ---- buffers ---------------------------------------------------------------------------------
+NFAI_API int32_t nfai_hip_buf_alloc(nfai_ctx_t h, uint64_t bytes, nfai_buf_t *out)
+{
+    CTX_OR_FAIL(c, h);
+    if (!out || bytes == 0) return fail(NFAI_ERR_INVALID, "buf_alloc: out null or zero bytes");
+    Buf *b = new Buf();
+    const uint64_t padded = (bytes + 255) & ~255ull;  // 16-byte vector accesses may touch the tail
+    hipError_t e = hipMalloc(&b->ptr, padded);
+    if (e != hipSuccess) {
+        delete b;
+        return fail(NFAI_ERR_OOM, "buf_alloc: hipMalloc(%llu) failed: %s", (unsigned long long)padded, hipGetErrorString(e));
+    }
+    HIP_TRY(hipMemsetAsync(b->ptr, 0, padded, c->stream));
+    b->bytes = bytes;
+    b->owned = true;
+    b->ctx = c;
+    handle_register(b);
+    *out = reinterpret_cast<nfai_buf_t>(b);
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_buf_wrap(nfai_ctx_t h, void *device_ptr, uint64_t bytes, nfai_buf_t *out)
+{
+    CTX_OR_FAIL(c, h);
+    if (!out || !device_ptr || bytes == 0) return fail(NFAI_ERR_INVALID, "buf_wrap: null argument");
+    if ((reinterpret_cast<uintptr_t>(device_ptr) & 15) != 0) return fail(NFAI_ERR_INVALID, "buf_wrap: pointer not 16-byte aligned");
+    Buf *b = new Buf();
+    b->ptr = device_ptr;
+    b->bytes = bytes;
+    b->owned = false;
+    b->ctx = c;
+    handle_register(b);
+    *out = reinterpret_cast<nfai_buf_t>(b);
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_buf_free(nfai_ctx_t h, nfai_buf_t bh)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(b, bh);
+    if (b->owned) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(b->ptr));
+    }
+    b->magic = 0;
+    handle_unregister(b);
+    delete b;
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_buf_upload(nfai_ctx_t h, nfai_buf_t bh, uint64_t off, const void *host, uint64_t bytes)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(b, bh);
+    if (!host || off + bytes > b->bytes) return fail(NFAI_ERR_INVALID, "buf_upload: range [%llu,+%llu) exceeds %llu",
+                                                     (unsigned long long)off, (unsigned long long)bytes, (unsigned long long)b->bytes);
+    HIP_TRY(hipMemcpyAsync(static_cast<char *>(b->ptr) + off, host, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_buf_download(nfai_ctx_t h, nfai_buf_t bh, uint64_t off, void *host, uint64_t bytes)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(b, bh);
+    if (!host || off + bytes > b->bytes) return fail(NFAI_ERR_INVALID, "buf_download: range [%llu,+%llu) exceeds %llu",
+                                                     (unsigned long long)off, (unsigned long long)bytes, (unsigned long long)b->bytes);
+    HIP_TRY(hipMemcpyAsync(host, static_cast<char *>(b->ptr) + off, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_buf_copy(nfai_ctx_t h, nfai_buf_t dh, uint64_t doff, nfai_buf_t sh, uint64_t soff, uint64_t bytes)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(d, dh);
+    BUF_OR_FAIL(s, sh);
+    if (doff + bytes > d->bytes || soff + bytes > s->bytes) return fail(NFAI_ERR_INVALID, "buf_copy: range out of bounds");
+    HIP_TRY(hipMemcpyAsync(static_cast<char *>(d->ptr) + doff, static_cast<char *>(s->ptr) + soff, bytes,
+                           hipMemcpyDeviceToDevice, c->stream));
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_buf_zero(nfai_ctx_t h, nfai_buf_t bh)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(b, bh);
+    HIP_TRY(hipMemsetAsync(b->ptr, 0, b->bytes, c->stream));
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_buf_info(nfai_ctx_t h, nfai_buf_t bh, void **ptr, uint64_t *bytes)
+{
+    CTX_OR_FAIL(c, h);
+    (void)c;
+    BUF_OR_FAIL(b, bh);
+    if (ptr) *ptr = b->ptr;
+    if (bytes) *bytes = b->bytes;
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_weight_bytes(int32_t type, uint64_t n_rows, uint64_t n_cols, uint64_t *bytes)
+{
+    const uint64_t rb = weight_row_bytes(type, n_cols);
+    if (rb == 0) return fail(NFAI_ERR_UNSUPPORTED, "weight_bytes: ggml type %d with %llu columns is not supported", type,
+                             (unsigned long long)n_cols);
+    if (bytes) *bytes = rb * n_rows;
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_weight_upload(nfai_ctx_t h, int32_t type, uint64_t n_rows, uint64_t n_cols, const void *host,
+                                        nfai_buf_t *out)
+{
+    uint64_t bytes = 0;
+    int rc = nfai_hip_weight_bytes(type, n_rows, n_cols, &bytes);
+    if (rc) return rc;
+    rc = nfai_hip_buf_alloc(h, bytes, out);
+    if (rc) return rc;
+    return nfai_hip_buf_upload(h, *out, 0, host, bytes);
+}
+
+// ---- 1:1 operators ---------------------------------------------------------------------------
+#define NEED(b, n_elems, esz)                                                                       \
+    if ((uint64_t)(n_elems) * (esz) > (b)->bytes)                                                   \
+        return fail(NFAI_ERR_INVALID, "%s: buffer %s holds %llu bytes, needs %llu", __func__, #b,   \
+                    (unsigned long long)(b)->bytes, (unsigned long long)((uint64_t)(n_elems) * (esz)))
+
+NFAI_API int32_t nfai_hip_embed(nfai_ctx_t h, nfai_buf_t table, int32_t type, nfai_buf_t tok, nfai_buf_t y, uint32_t E)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(bt, table);
+    BUF_OR_FAIL(bk, tok);
+    BUF_OR_FAIL(by, y);
+    if (type != NFAI_F16 && type != NFAI_F32) return fail(NFAI_ERR_UNSUPPORTED, "embed: table type %d", type);
+    NEED(bk, 1, 4);
+    NEED(by, E, 4);
+    LAUNCH_TRY(launch_embed(bt->ptr, type, static_cast<const uint32_t *>(bk->ptr), static_cast<float *>(by->ptr), E, c->stream));
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_rmsnorm(nfai_ctx_t h, nfai_buf_t x, nfai_buf_t g, nfai_buf_t y, uint32_t E, float eps)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(bx, x);
+    BUF_OR_FAIL(bg, g);
+    BUF_OR_FAIL(by, y);
+    NEED(bx, E, 4);
+    NEED(bg, E, 4);
+    NEED(by, E, 4);
+    LAUNCH_TRY(launch_rmsnorm(static_cast<const float *>(bx->ptr), static_cast<const float *>(bg->ptr),
+                              static_cast<float *>(by->ptr), E, eps, c->stream));
+    return NFAI_OK;
+}
+
+static int gemv_common(Ctx *c, GemvArgs &a, const char *fn)
+{
+    a.n_cu = (uint32_t)c->prop.multiProcessorCount;
+    hipError_t e = launch_gemv(a, c->stream);
+    if (e == hipErrorInvalidValue)
+        return fail(NFAI_ERR_INVALID, "%s: unsupported GEMV shape/type (type %d, K %u; fp16 needs K %% 8 == 0)", fn, a.w_type, a.K);
+    if (e != hipSuccess) return fail(NFAI_ERR_HIP, "%s: launch failed: %s", fn, hipGetErrorString(e));
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_gemv(nfai_ctx_t h, nfai_buf_t W, int32_t type, nfai_buf_t x, nfai_buf_t y, uint64_t y_off,
+                               uint32_t N, uint32_t K)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(bw, W);
+    BUF_OR_FAIL(bx, x);
+    BUF_OR_FAIL(by, y);
+    const uint64_t rb = weight_row_bytes(type, K);
+    if (rb == 0) return fail(NFAI_ERR_UNSUPPORTED, "gemv: ggml type %d with K=%u is not supported", type, K);
+    NEED(bw, (uint64_t)N * rb, 1);
+    NEED(bx, K, 4);
+    NEED(by, y_off + N, 4);
+    GemvArgs a;
+    a.W[0] = bw->ptr;
+    a.seg_rows[0] = N;
+    a.w_type = type;
+    a.x = static_cast<const float *>(bx->ptr);
+    a.K = K;
+    a.mode = GEMV_PLAIN;
+    a.y = static_cast<float *>(by->ptr) + y_off;
+    return gemv_common(c, a, __func__);
+}
+
+NFAI_API int32_t nfai_hip_rope(nfai_ctx_t h, nfai_buf_t in, uint64_t in_off, nfai_buf_t out, uint64_t out_off,
+                               nfai_buf_t freqs, uint32_t rope_dims, uint32_t n_heads, uint32_t head_dim, uint32_t pos)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(bi, in);
+    BUF_OR_FAIL(bo, out);
+    BUF_OR_FAIL(bf, freqs);
+    if (head_dim % 2) return fail(NFAI_ERR_INVALID, "rope: odd head_dim");
+    const uint64_t n = (uint64_t)n_heads * head_dim;
+    NEED(bi, in_off + n, 4);
+    NEED(bo, out_off + n, 4);
+    NEED(bf, (rope_dims < head_dim ? rope_dims : head_dim) / 2, 4);
+    LAUNCH_TRY(launch_rope(static_cast<const float *>(bi->ptr) + in_off, static_cast<float *>(bo->ptr) + out_off,
+                           static_cast<const float *>(bf->ptr), rope_dims, n_heads, head_dim, pos, c->stream));
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_attn_scores(nfai_ctx_t h, nfai_buf_t q, nfai_buf_t kc, nfai_buf_t s, uint32_t H, uint32_t Hkv,
+                                      uint32_t D, uint32_t S)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(bq, q);
+    BUF_OR_FAIL(bk, kc);
+    BUF_OR_FAIL(bs, s);
+    if (Hkv == 0 || H % Hkv || S == 0) return fail(NFAI_ERR_INVALID, "attn_scores: H=%u Hkv=%u S=%u", H, Hkv, S);
+    NEED(bq, (uint64_t)H * D, 4);
+    NEED(bk, (uint64_t)S * Hkv * D, 4);
+    NEED(bs, (uint64_t)H * S, 4);
+    LAUNCH_TRY(launch_attn_scores(static_cast<const float *>(bq->ptr), static_cast<const float *>(bk->ptr),
+                                  static_cast<float *>(bs->ptr), H, Hkv, D, S, c->stream));
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_attn_softmax(nfai_ctx_t h, nfai_buf_t s, nfai_buf_t w, uint32_t H, uint32_t S, float eps)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(bs, s);
+    BUF_OR_FAIL(bw, w);
+    if (S == 0) return fail(NFAI_ERR_INVALID, "attn_softmax: S=0");
+    NEED(bs, (uint64_t)H * S, 4);
+    NEED(bw, (uint64_t)H * S, 4);
+    LAUNCH_TRY(launch_attn_softmax(static_cast<const float *>(bs->ptr), static_cast<float *>(bw->ptr), H, S, eps, c->stream));
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_attn_wsum(nfai_ctx_t h, nfai_buf_t w, nfai_buf_t vc, nfai_buf_t o, uint32_t H, uint32_t Hkv,
+                                    uint32_t D, uint32_t S)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(bw, w);
+    BUF_OR_FAIL(bv, vc);
+    BUF_OR_FAIL(bo, o);
+    if (Hkv == 0 || H % Hkv || S == 0) return fail(NFAI_ERR_INVALID, "attn_wsum: H=%u Hkv=%u S=%u", H, Hkv, S);
+    NEED(bw, (uint64_t)H * S, 4);
+    NEED(bv, (uint64_t)S * Hkv * D, 4);
+    NEED(bo, (uint64_t)H * D, 4);
+    LAUNCH_TRY(launch_attn_wsum(static_cast<const float *>(bw->ptr), static_cast<const float *>(bv->ptr),
+                                static_cast<float *>(bo->ptr), H, Hkv, D, S, c->stream));
+    return NFAI_OK;
+}
+
+#define ELTWISE2(name, launch)                                                                              \
+    NFAI_API int32_t name(nfai_ctx_t h, nfai_buf_t a, nfai_buf_t b, nfai_buf_t y, uint32_t n)                \
+    {                                                                                                       \
+        CTX_OR_FAIL(c, h);                                                                                  \
+        BUF_OR_FAIL(ba, a);                                                                                 \
+        BUF_OR_FAIL(bb, b);                                                                                 \
+        BUF_OR_FAIL(by, y);                                                                                 \
+        NEED(ba, n, 4);                                                                                     \
+        NEED(bb, n, 4);                                                                                     \
+        NEED(by, n, 4);                                                                                     \
+        LAUNCH_TRY(launch(static_cast<const float *>(ba->ptr), static_cast<const float *>(bb->ptr),        \
+                          static_cast<float *>(by->ptr), n, c->stream));                                    \
+        return NFAI_OK;                                                                                     \
+    }
+ELTWISE2(nfai_hip_mul, launch_mul)
+ELTWISE2(nfai_hip_add, launch_add)
+
+NFAI_API int32_t nfai_hip_silu(nfai_ctx_t h, nfai_buf_t x, nfai_buf_t y, uint32_t n)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(bx, x);
+    BUF_OR_FAIL(by, y);
+    NEED(bx, n, 4);
+    NEED(by, n, 4);
+    LAUNCH_TRY(launch_silu(static_cast<const float *>(bx->ptr), static_cast<float *>(by->ptr), n, c->stream));
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_argmax(nfai_ctx_t h, nfai_buf_t x, uint32_t n, nfai_buf_t out_idx)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(bx, x);
+    BUF_OR_FAIL(bo, out_idx);
+    if (n == 0) return fail(NFAI_ERR_INVALID, "argmax: n=0");
+    NEED(bx, n, 4);
+    NEED(bo, 1, 4);
+    LAUNCH_TRY(launch_argmax(static_cast<const float *>(bx->ptr), n, static_cast<uint32_t *>(bo->ptr), c->scratch, nullptr,
+                             nullptr, 0, c->stream));
+    return NFAI_OK;
+}
+
+// ---- fused operators -------------------------------------------------------------------------
+// Scalars the fused kernels read from device memory (so graphs can be replayed) live at the END
+// of the context scratch area when the op-level entry points are used.
+static uint32_t *scratch_pos(Ctx *c) { return reinterpret_cast<uint32_t *>(static_cast<char *>(c->scratch) + c->scratch_bytes - 256); }
+static float *scratch_ropecs(Ctx *c) { return reinterpret_cast<float *>(static_cast<char *>(c->scratch) + c->scratch_bytes - 4096); }
+static float *scratch_attn(Ctx *c) { return reinterpret_cast<float *>(static_cast<char *>(c->scratch) + 8192); }
+
+NFAI_API int32_t nfai_hip_attn_decode(nfai_ctx_t h, nfai_buf_t q, nfai_buf_t kc, nfai_buf_t vc, nfai_buf_t o, uint32_t H,
+                                      uint32_t Hkv, uint32_t D, uint32_t S, uint32_t C, int32_t kv_type)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(bq, q);
+    BUF_OR_FAIL(bk, kc);
+    BUF_OR_FAIL(bv, vc);
+    BUF_OR_FAIL(bo, o);
+    if (S == 0 || S > C) return fail(NFAI_ERR_INVALID, "attn_decode: S=%u outside (0, C=%u]", S, C);
+    if (kv_type != NFAI_F32 && kv_type != NFAI_F16) return fail(NFAI_ERR_UNSUPPORTED, "attn_decode: kv type %d", kv_type);
+    const uint32_t esz = kv_type == NFAI_F16 ? 2 : 4;
+    NEED(bq, (uint64_t)H * D, 4);
+    NEED(bk, (uint64_t)S * Hkv * D, esz);
+    NEED(bv, (uint64_t)S * Hkv * D, esz);
+    NEED(bo, (uint64_t)H * D, 4);
+    if (attn_partials_bytes(H, Hkv, D) + 8192 + 4096 > c->scratch_bytes) return fail(NFAI_ERR_INVALID, "attn_decode: H*D too large for scratch");
+    const uint32_t pos = S - 1;
+    HIP_TRY(hipMemcpyAsync(scratch_pos(c), &pos, 4, hipMemcpyHostToDevice, c->stream));
+    AttnArgs a;
+    a.q = static_cast<const float *>(bq->ptr);
+    a.kcache = bk->ptr;
+    a.vcache = bv->ptr;
+    a.kv_type = kv_type;
+    a.kv_pos_stride = (uint64_t)Hkv * D;
+    a.kv_head_stride = D;
+    a.o = static_cast<float *>(bo->ptr);
+    a.H = H; a.Hkv = Hkv; a.D = D; a.C = C;
+    a.pos_dev = scratch_pos(c);
+    a.partials = scratch_attn(c);
+    hipError_t e = launch_attn_decode(a, c->stream);
+    if (e == hipErrorInvalidValue) return fail(NFAI_ERR_INVALID, "attn_decode: unsupported shape (D must be 64 or 128, H/Hkv <= 8, C <= 32768)");
+    if (e != hipSuccess) return fail(NFAI_ERR_HIP, "attn_decode: launch failed: %s", hipGetErrorString(e));
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_gemv_fused(nfai_ctx_t h, nfai_buf_t W, int32_t type, nfai_buf_t x, nfai_buf_t gamma, float eps,
+                                     nfai_buf_t res, nfai_buf_t y, uint32_t N, uint32_t K)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(bw, W);
+    BUF_OR_FAIL(bx, x);
+    BUF_OR_FAIL(by, y);
+    Buf *bg = gamma ? buf_of(gamma) : nullptr;
+    Buf *br = res ? buf_of(res) : nullptr;
+    if ((gamma && !bg) || (res && !br)) return fail(NFAI_ERR_INVALID, "gemv_fused: invalid gamma/res handle");
+    const uint64_t rb = weight_row_bytes(type, K);
+    if (rb == 0) return fail(NFAI_ERR_UNSUPPORTED, "gemv_fused: ggml type %d with K=%u is not supported", type, K);
+    NEED(bw, (uint64_t)N * rb, 1);
+    NEED(bx, K, 4);
+    NEED(by, N, 4);
+    if (bg) NEED(bg, K, 4);
+    if (br) NEED(br, N, 4);
+    GemvArgs a;
+    a.W[0] = bw->ptr;
+    a.seg_rows[0] = N;
+    a.w_type = type;
+    a.x = static_cast<const float *>(bx->ptr);
+    a.gamma = bg ? static_cast<const float *>(bg->ptr) : nullptr;
+    a.eps = eps;
+    a.K = K;
+    a.mode = br ? GEMV_RESIDUAL : GEMV_PLAIN;
+    a.res = br ? static_cast<const float *>(br->ptr) : nullptr;
+    a.y = static_cast<float *>(by->ptr);
+    return gemv_common(c, a, __func__);
+}
+
+NFAI_API int32_t nfai_hip_gemv_gateup_silu(nfai_ctx_t h, nfai_buf_t Wg, nfai_buf_t Wu, int32_t type, nfai_buf_t x,
+                                           nfai_buf_t gamma, float eps, nfai_buf_t y, uint32_t F, uint32_t K)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(bg_, Wg);
+    BUF_OR_FAIL(bu, Wu);
+    BUF_OR_FAIL(bx, x);
+    BUF_OR_FAIL(by, y);
+    Buf *bg = gamma ? buf_of(gamma) : nullptr;
+    if (gamma && !bg) return fail(NFAI_ERR_INVALID, "gemv_gateup_silu: invalid gamma handle");
+    const uint64_t rb = weight_row_bytes(type, K);
+    if (rb == 0) return fail(NFAI_ERR_UNSUPPORTED, "gemv_gateup_silu: ggml type %d with K=%u is not supported", type, K);
+    NEED(bg_, (uint64_t)F * rb, 1);
+    NEED(bu, (uint64_t)F * rb, 1);
+    NEED(bx, K, 4);
+    NEED(by, F, 4);
+    if (bg) NEED(bg, K, 4);
+    GemvArgs a;
+    a.W[0] = bg_->ptr;
+    a.W[1] = bu->ptr;
+    a.seg_rows[0] = a.seg_rows[1] = F;
+    a.w_type = type;
+    a.x = static_cast<const float *>(bx->ptr);
+    a.gamma = bg ? static_cast<const float *>(bg->ptr) : nullptr;
+    a.eps = eps;
+    a.K = K;
+    a.mode = GEMV_GATEUP;
+    a.y = static_cast<float *>(by->ptr);
+    return gemv_common(c, a, __func__);
+}
+
+NFAI_API int32_t nfai_hip_gemv_qkv_rope(nfai_ctx_t h, nfai_buf_t Wq, nfai_buf_t Wk, nfai_buf_t Wv, int32_t type,
+                                        nfai_buf_t x, nfai_buf_t gamma, float eps, nfai_buf_t freqs, uint32_t rope_dims,
+                                        nfai_buf_t q, nfai_buf_t kc, nfai_buf_t vc, uint32_t H, uint32_t Hkv, uint32_t D,
+                                        uint32_t pos, int32_t kv_type, uint32_t E)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(bq_, Wq);
+    BUF_OR_FAIL(bk_, Wk);
+    BUF_OR_FAIL(bv_, Wv);
+    BUF_OR_FAIL(bx, x);
+    BUF_OR_FAIL(bf, freqs);
+    BUF_OR_FAIL(bq, q);
+    BUF_OR_FAIL(bk, kc);
+    BUF_OR_FAIL(bv, vc);
+    Buf *bg = gamma ? buf_of(gamma) : nullptr;
+    if (gamma && !bg) return fail(NFAI_ERR_INVALID, "gemv_qkv_rope: invalid gamma handle");
+    if (kv_type != NFAI_F32 && kv_type != NFAI_F16) return fail(NFAI_ERR_UNSUPPORTED, "gemv_qkv_rope: kv type %d", kv_type);
+    const uint64_t rb = weight_row_bytes(type, E);
+    if (rb == 0) return fail(NFAI_ERR_UNSUPPORTED, "gemv_qkv_rope: ggml type %d with K=%u is not supported", type, E);
+    const uint32_t esz = kv_type == NFAI_F16 ? 2 : 4;
+    const uint32_t nfreq = (rope_dims < D ? rope_dims : D) / 2;
+    NEED(bq_, (uint64_t)H * D * rb, 1);
+    NEED(bk_, (uint64_t)Hkv * D * rb, 1);
+    NEED(bv_, (uint64_t)Hkv * D * rb, 1);
+    NEED(bx, E, 4);
+    NEED(bf, nfreq, 4);
+    NEED(bq, (uint64_t)H * D, 4);
+    NEED(bk, ((uint64_t)pos + 1) * Hkv * D, esz);
+    NEED(bv, ((uint64_t)pos + 1) * Hkv * D, esz);
+    if (bg) NEED(bg, E, 4);
+    if (nfreq * 8 > 3072) return fail(NFAI_ERR_INVALID, "gemv_qkv_rope: rope_dims too large");
+    HIP_TRY(hipMemcpyAsync(scratch_pos(c), &pos, 4, hipMemcpyHostToDevice, c->stream));
+    LAUNCH_TRY(launch_token_begin(nullptr, 0, nullptr, nullptr, 0, static_cast<const float *>(bf->ptr), scratch_ropecs(c), nfreq,
+                                  scratch_pos(c), c->stream));
+    GemvArgs a;
+    a.W[0] = bq_->ptr; a.W[1] = bk_->ptr; a.W[2] = bv_->ptr;
+    a.seg_rows[0] = H * D; a.seg_rows[1] = Hkv * D; a.seg_rows[2] = Hkv * D;
+    a.w_type = type;
+    a.x = static_cast<const float *>(bx->ptr);
+    a.gamma = bg ? static_cast<const float *>(bg->ptr) : nullptr;
+    a.eps = eps;
+    a.K = E;
+    a.mode = GEMV_QKV_ROPE;
+    a.y = static_cast<float *>(bq->ptr);
+    a.kcache = bk->ptr; a.vcache = bv->ptr;
+    a.kv_type = kv_type;
+    a.kv_pos_stride = (uint64_t)Hkv * D;
+    a.kv_head_stride = D;
+    a.rope_cs = scratch_ropecs(c);
+    a.rope_dims = rope_dims; a.H = H; a.Hkv = Hkv; a.D = D;
+    a.pos_dev = scratch_pos(c);
+    return gemv_common(c, a, __func__);
+}

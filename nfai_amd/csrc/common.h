@@ -1,0 +1,223 @@
+// common.h — shared host/device helpers of libnfai_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/nfai_hip.h"
+
+#define NFAI_API extern "C" __attribute__((visibility("default")))
+
+namespace nfai {
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+int fail(int code, const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return nfai::fail(_e == hipErrorOutOfMemory ? NFAI_ERR_OOM : NFAI_ERR_HIP,         \
+                              "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                              __LINE__);                                                       \
+    } while (0)
+
+#define NFAI_REQUIRE(cond, ...)                                      \
+    do {                                                             \
+        if (!(cond)) return nfai::fail(NFAI_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+// ---- handles --------------------------------------------------------------------------------
+struct Ctx {
+    uint32_t magic = 0x4E464358;  // 'NFCX'
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = true;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipDeviceProp_t prop;
+    void *scratch = nullptr;  // small workspace for ops that need one (argmax partials, attention partials)
+    size_t scratch_bytes = 0;
+};
+
+struct Buf {
+    uint32_t magic = 0x4E464246;  // 'NFBF'
+    void *ptr = nullptr;
+    uint64_t bytes = 0;
+    bool owned = true;
+    Ctx *ctx = nullptr;
+};
+
+Ctx *ctx_of(nfai_ctx_t h);
+Buf *buf_of(nfai_buf_t h);
+void handle_register(const void *p);
+void handle_unregister(const void *p);
+bool handle_live(uint64_t h);
+
+uint64_t weight_row_bytes(int ggml_type, uint64_t n_cols);  // 0 if unsupported / misaligned
+
+// ---- launch entry points implemented in the kernel translation units --------------------------
+// Plain pointers; every function enqueues on `s` and returns hipGetLastError().
+struct GemvArgs {
+    // up to three weight segments (QKV) or two (gate/up); rows are [seg_rows[i]] each, all K wide
+    const void *W[3] = {nullptr, nullptr, nullptr};
+    uint32_t seg_rows[3] = {0, 0, 0};
+    int w_type = NFAI_F16;
+    const float *x = nullptr;      // K floats
+    const float *gamma = nullptr;  // non-null => RMSNorm(x, gamma, eps) prologue
+    float eps = 0.f;
+    uint32_t K = 0;
+    // epilogues
+    int mode = 0;                  // GemvMode
+    float *y = nullptr;            // PLAIN/RESIDUAL/GATEUP output, QKV: q output (H*D)
+    const float *res = nullptr;    // RESIDUAL
+    // QKV
+    void *kcache = nullptr, *vcache = nullptr;  // layer base pointers
+    int kv_type = NFAI_F32;
+    uint64_t kv_pos_stride = 0;    // elements between consecutive positions
+    uint64_t kv_head_stride = 0;   // elements between consecutive kv heads
+    const float *rope_cs = nullptr;  // [rope_dims/2][2] cos,sin for the current position (device)
+    uint32_t rope_dims = 0, H = 0, Hkv = 0, D = 0;
+    const uint32_t *pos_dev = nullptr;  // current position (device scalar)
+    // optional fused argmax partials (lm_head)
+    uint32_t n_cu = 256;
+};
+enum GemvMode { GEMV_PLAIN = 0, GEMV_RESIDUAL = 1, GEMV_QKV_ROPE = 2, GEMV_GATEUP = 3 };
+
+hipError_t launch_gemv(const GemvArgs &a, hipStream_t s);
+
+struct AttnArgs {
+    const float *q = nullptr;  // [H][D] fp32 (after RoPE)
+    const void *kcache = nullptr, *vcache = nullptr;
+    int kv_type = NFAI_F32;
+    uint64_t kv_pos_stride = 0, kv_head_stride = 0;
+    float *o = nullptr;        // [H][D]
+    uint32_t H = 0, Hkv = 0, D = 0, C = 0;
+    const uint32_t *pos_dev = nullptr;  // S = *pos_dev + 1
+    float *partials = nullptr;          // workspace: [Hkv][NSPLIT_MAX][G*(D+2)]
+    uint32_t n_cu = 256;
+};
+constexpr uint32_t ATTN_NSPLIT_MAX = 32;
+size_t attn_partials_bytes(uint32_t H, uint32_t Hkv, uint32_t D);
+hipError_t launch_attn_decode(const AttnArgs &a, hipStream_t s);
+
+// basic 1:1 ops
+hipError_t launch_embed(const void *table, int type, const uint32_t *tok, float *y, uint32_t E, hipStream_t s);
+hipError_t launch_rmsnorm(const float *x, const float *g, float *y, uint32_t E, float eps, hipStream_t s);
+hipError_t launch_rope(const float *in, float *out, const float *freqs, uint32_t rope_dims, uint32_t n_heads,
+                       uint32_t head_dim, uint32_t pos, hipStream_t s);
+hipError_t launch_attn_scores(const float *q, const float *K, float *sc, uint32_t H, uint32_t Hkv, uint32_t D,
+                              uint32_t S, hipStream_t s);
+hipError_t launch_attn_softmax(const float *sc, float *w, uint32_t H, uint32_t S, float eps, hipStream_t s);
+hipError_t launch_attn_wsum(const float *w, const float *V, float *o, uint32_t H, uint32_t Hkv, uint32_t D,
+                            uint32_t S, hipStream_t s);
+hipError_t launch_silu(const float *x, float *y, uint32_t n, hipStream_t s);
+hipError_t launch_mul(const float *a, const float *b, float *y, uint32_t n, hipStream_t s);
+hipError_t launch_add(const float *a, const float *b, float *y, uint32_t n, hipStream_t s);
+// argmax over n floats -> out_idx; `partials` needs 2*ARGMAX_BLOCKS*4 bytes. If pos_inc != null it is
+// incremented by the final block (end-of-token bookkeeping for graph replay); ring != null records
+// the token at ring[(*pos_inc_old) % ring_len].
+constexpr uint32_t ARGMAX_BLOCKS = 128;
+hipError_t launch_argmax(const float *x, uint32_t n, uint32_t *out_idx, void *partials, uint32_t *pos_inc,
+                         uint32_t *ring, uint32_t ring_len, hipStream_t s);
+// per-token prologue: embed row -> x, cos/sin table for the current position
+hipError_t launch_token_begin(const void *table, int type, const uint32_t *tok, float *x, uint32_t E,
+                              const float *freqs, float *rope_cs, uint32_t n_freq, const uint32_t *pos_dev,
+                              hipStream_t s);
+hipError_t launch_pos_advance(uint32_t *pos_dev, hipStream_t s);
+
+}  // namespace nfai
+
+// ---- device helpers (HIP translation units only) ------------------------------------------------
+#if defined(__HIPCC__)
+namespace nfai {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int WAVE = 64;
+
+// Sum across the 64 lanes of a wave; every lane gets the total.
+// DPP within rows of 16 (quad_perm xor1, xor2; row_half_mirror; row_mirror), then the four row
+// totals are read with v_readlane (wave-uniform) and added.
+__device__ __forceinline__ float wave_sum(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    int iv = __builtin_bit_cast(int, v);
+    float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+    float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+    float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// Sum within aligned groups of `width` lanes (power of two <= 64); every lane of the group gets it.
+template <int width>
+__device__ __forceinline__ float group_sum(float v)
+{
+#pragma unroll
+    for (int o = width / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// 16-byte streaming load of read-once data (weights, KV): non-temporal so it does not displace
+// the activations in L2 (MI355X guide, row nt-weights).
+__device__ __forceinline__ u32x4 load_nt16(const void *p)
+{
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+}
+
+__device__ __forceinline__ float h2f_lo(uint32_t w) { return (float)__builtin_bit_cast(f16x2, w)[0]; }
+__device__ __forceinline__ float h2f_hi(uint32_t w) { return (float)__builtin_bit_cast(f16x2, w)[1]; }
+
+// dot of 8 fp16 weights (one 16-byte load) with 8 fp32 activations, fp32 accumulate.
+// fmaf((float)h, x, acc) lowers to v_fma_mix_f32 (fp16 operand converted inside the FMA).
+__device__ __forceinline__ float dot8_f16(u32x4 w, f32x4 x0, f32x4 x1, float acc)
+{
+    acc = fmaf(h2f_lo(w[0]), x0[0], acc);
+    acc = fmaf(h2f_hi(w[0]), x0[1], acc);
+    acc = fmaf(h2f_lo(w[1]), x0[2], acc);
+    acc = fmaf(h2f_hi(w[1]), x0[3], acc);
+    acc = fmaf(h2f_lo(w[2]), x1[0], acc);
+    acc = fmaf(h2f_hi(w[2]), x1[1], acc);
+    acc = fmaf(h2f_lo(w[3]), x1[2], acc);
+    acc = fmaf(h2f_hi(w[3]), x1[3], acc);
+    return acc;
+}
+
+__device__ __forceinline__ float silu_ref(float x)
+{
+    // SiLUShader.cs:121-123: x * (1.0 / (1.0 + exp(-x)))
+    float sig = 1.0f / (1.0f + expf(-x));
+    return x * sig;
+}
+
+// Block-wide sum (<= 16 waves); every thread gets the total.  `red` is >= 16 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float *red)
+{
+    v = wave_sum(v);
+    const int wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wid] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; i++) t += red[i];
+    return t;
+}
+
+}  // namespace nfai
+#endif

@@ -1,0 +1,386 @@
+// kernels_gemv.hip — the weight-streaming GEMV family: MatrixMultiplyShader at M = 1
+// (MatrixMultiplyShader.cs:255-289) rewritten for gfx950, with the neighbouring small ops of
+// TransformerBlock.Compute (TransformerBlock.cs:127-184) fused in as prologue / epilogue.
+//
+// Bound: HBM.  Every weight byte is read exactly once per token, straight HBM -> VGPR with
+// 16-byte non-temporal loads (one wave-instruction = one contiguous 1 KiB piece of a row); the
+// weights never touch LDS (MI355X guide, "GEMV / M <= 16" row: an LDS round trip of once-read
+// data is pure overhead).  LDS holds only what is re-used: the activation vector x (after the
+// optional RMSNorm), laid out so each lane's ds_read_b128 is conflict-free.
+//
+//  work unit   = one output row, or a row PAIR that an epilogue needs together
+//                (RoPE rotates rows 2i,2i+1; SiLU*up needs gate row j and up row j)
+//  wave        = a contiguous, balanced range of units; walks them UPW units at a time as a flat
+//                sequence of (unit group, K-chunk group) steps with the next step's loads issued
+//                before the current step's FMAs (register double buffer) so R*U 1-KiB loads per
+//                wave are always in flight, across row boundaries too
+//  block       = 4..8 waves sharing x in LDS; grid = one or two blocks per CU, sized by the
+//                host so that units divide evenly over all waves (no tail wave)
+#include "common.h"
+
+namespace nfai {
+
+struct GemvParams {
+    const uint8_t *W[3];
+    uint32_t seg_end[3];   // QKV: cumulative row ends of the q / k / v segments
+    uint64_t row_bytes;
+    const float *x;
+    const float *gamma;
+    float eps;
+    uint32_t K, KC, NU;
+    float *y;
+    const float *res;
+    void *kc, *vc;
+    uint64_t kv_pos_stride, kv_head_stride;
+    const float *rope_cs;
+    uint32_t rope_dims, D;
+    const uint32_t *pos;
+    int kv_f16;
+};
+
+template <int WT> struct WTraits;
+template <> struct WTraits<NFAI_F16> { static constexpr int EPL = 8; };  // elements per 16-byte lane load
+template <> struct WTraits<NFAI_F32> { static constexpr int EPL = 4; };
+
+// LDS index of activation element k (see header: two 1-KiB planes per 512-element chunk for fp16
+// weights so that lane l's two float4 reads sit at l*16 bytes in each plane).
+template <int EPL> __device__ __forceinline__ uint32_t xs_index(uint32_t k)
+{
+    if constexpr (EPL == 8) {
+        const uint32_t chunk = k >> 9, within = k & 511;
+        return (chunk << 9) + (((within >> 2) & 1) << 8) + ((within >> 3) << 2) + (within & 3);
+    } else {
+        return k;
+    }
+}
+
+template <int WT, int U, bool GUARD>
+__device__ __forceinline__ void issue_loads(u32x4 (&dst)[U], const uint8_t *row, uint32_t chunk0, uint32_t lane,
+                                            uint32_t K)
+{
+    constexpr int EPL = WTraits<WT>::EPL;
+    constexpr int EB = (WT == NFAI_F16) ? 2 : 4;
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+        const uint32_t k = (chunk0 + j) * (64 * EPL) + lane * EPL;
+        if constexpr (GUARD) {
+            if (k + EPL <= K) dst[j] = load_nt16(row + (uint64_t)k * EB);
+            else dst[j] = u32x4{0, 0, 0, 0};
+        } else {
+            dst[j] = load_nt16(row + (uint64_t)k * EB);
+        }
+    }
+}
+
+template <int WT>
+__device__ __forceinline__ float dot_chunk(u32x4 w, const float *xs, uint32_t chunk, uint32_t lane, float acc)
+{
+    if constexpr (WT == NFAI_F16) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4 *>(xs + (chunk << 9) + (lane << 2));
+        const f32x4 x1 = *reinterpret_cast<const f32x4 *>(xs + (chunk << 9) + 256 + (lane << 2));
+        return dot8_f16(w, x0, x1, acc);
+    } else {
+        const f32x4 x0 = *reinterpret_cast<const f32x4 *>(xs + (chunk << 8) + (lane << 2));
+        acc = fmaf(__builtin_bit_cast(float, w[0]), x0[0], acc);
+        acc = fmaf(__builtin_bit_cast(float, w[1]), x0[1], acc);
+        acc = fmaf(__builtin_bit_cast(float, w[2]), x0[2], acc);
+        acc = fmaf(__builtin_bit_cast(float, w[3]), x0[3], acc);
+        return acc;
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ const uint8_t *row_ptr(const GemvParams &p, uint32_t unit, int sub)
+{
+    if constexpr (MODE == GEMV_GATEUP) {
+        return p.W[sub] + (uint64_t)unit * p.row_bytes;  // sub 0 = gate row, 1 = up row
+    } else if constexpr (MODE == GEMV_QKV_ROPE) {
+        const uint32_t row = unit * 2 + sub;
+        if (row < p.seg_end[0]) return p.W[0] + (uint64_t)row * p.row_bytes;
+        if (row < p.seg_end[1]) return p.W[1] + (uint64_t)(row - p.seg_end[0]) * p.row_bytes;
+        return p.W[2] + (uint64_t)(row - p.seg_end[1]) * p.row_bytes;
+    } else {
+        return p.W[0] + (uint64_t)unit * p.row_bytes;
+    }
+}
+
+__device__ __forceinline__ void kv_store(void *base, int f16, uint64_t idx, float v)
+{
+    if (f16) reinterpret_cast<_Float16 *>(base)[idx] = (_Float16)v;
+    else reinterpret_cast<float *>(base)[idx] = v;
+}
+
+// Epilogue of one unit; called by one lane with the fully reduced sums.
+template <int MODE>
+__device__ __forceinline__ void epilogue(const GemvParams &p, uint32_t unit, float a0, float a1)
+{
+    if constexpr (MODE == GEMV_PLAIN) {
+        p.y[unit] = a0;
+    } else if constexpr (MODE == GEMV_RESIDUAL) {
+        // host residual add of TransformerBlock.cs:153-158 / 176-180: input + projection
+        p.y[unit] = p.res[unit] + a0;
+    } else if constexpr (MODE == GEMV_GATEUP) {
+        // SiLUShader.cs:121-123 on the gate, ElementWiseMultiplicationShader.cs:137 with A = up
+        p.y[unit] = a1 * silu_ref(a0);
+    } else {
+        // RoPEShader.cs:249-262 on the pair (row, row+1); V rows are stored unrotated
+        const uint32_t row = unit * 2;
+        const uint32_t seg = row < p.seg_end[0] ? 0u : (row < p.seg_end[1] ? 1u : 2u);
+        const uint32_t r = seg == 0 ? row : (seg == 1 ? row - p.seg_end[0] : row - p.seg_end[1]);
+        const uint32_t head = r / p.D, d = r % p.D;
+        float o0 = a0, o1 = a1;
+        if (seg < 2 && d < p.rope_dims) {
+            const float c = p.rope_cs[d], sn = p.rope_cs[d + 1];  // [pair][2] with pair = d/2
+            o0 = c * a0 - sn * a1;
+            o1 = sn * a0 + c * a1;
+        }
+        if (seg == 0) {
+            p.y[row] = o0;
+            p.y[row + 1] = o1;
+        } else {
+            const uint64_t idx = (uint64_t)p.pos[0] * p.kv_pos_stride + (uint64_t)head * p.kv_head_stride + d;
+            void *base = seg == 1 ? p.kc : p.vc;
+            kv_store(base, p.kv_f16, idx, o0);
+            kv_store(base, p.kv_f16, idx + 1, o1);
+        }
+    }
+}
+
+template <int WT, int MODE, int UPW, int U, bool GUARD>
+__global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
+{
+    constexpr int RPU = (MODE == GEMV_QKV_ROPE || MODE == GEMV_GATEUP) ? 2 : 1;
+    constexpr int R = UPW * RPU;
+    constexpr int EPL = WTraits<WT>::EPL;
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // KC*64*EPL floats, then 16 for reductions
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t nwaves = blockDim.x >> 6;
+    const uint32_t wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t gw = blockIdx.x * nwaves + wid, tw = gridDim.x * nwaves;
+    const uint32_t u_begin = (uint32_t)(((uint64_t)p.NU * gw) / tw);
+    const uint32_t u_end = (uint32_t)(((uint64_t)p.NU * (gw + 1)) / tw);
+    const uint32_t ngroups = (u_end - u_begin + UPW - 1) / UPW;
+    const uint32_t cpg = p.KC / U;  // K-chunk groups per unit group
+    const uint32_t nsteps = ngroups * cpg;
+
+    u32x4 cur[R][U], nxt[R][U];
+    const uint8_t *rows[R];
+    // ---- first step's weight loads go out before anything else: they do not depend on x ----
+    if (nsteps > 0) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t u = min(u_begin + r / RPU, u_end - 1);
+            rows[r] = row_ptr<MODE>(p, u, r % RPU);
+            issue_loads<WT, U, GUARD>(cur[r], rows[r], 0, lane, p.K);
+        }
+    }
+
+    // ---- prologue: x (optionally RMSNorm'd: RMSNormShader.cs:136-149) -> LDS -----------------
+    {
+        const uint32_t kpad = p.KC * 64 * EPL;
+        float *red = xs + kpad;
+        float inv_rms = 1.f;
+        if (p.gamma != nullptr) {
+            float ss = 0.f;
+            for (uint32_t k = threadIdx.x * 4; k < p.K; k += blockDim.x * 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(p.x + k);
+                ss = fmaf(v[0], v[0], ss);
+                ss = fmaf(v[1], v[1], ss);
+                ss = fmaf(v[2], v[2], ss);
+                ss = fmaf(v[3], v[3], ss);
+            }
+            ss = block_sum(ss, red);
+            inv_rms = sqrtf(ss / (float)p.K + p.eps);  // rms itself; applied as a division below
+        }
+        for (uint32_t k = threadIdx.x * 4; k < kpad; k += blockDim.x * 4) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < p.K) {
+                v = *reinterpret_cast<const f32x4 *>(p.x + k);
+                if (p.gamma != nullptr) {
+                    const f32x4 g = *reinterpret_cast<const f32x4 *>(p.gamma + k);
+                    v[0] = (v[0] / inv_rms) * g[0];
+                    v[1] = (v[1] / inv_rms) * g[1];
+                    v[2] = (v[2] / inv_rms) * g[2];
+                    v[3] = (v[3] / inv_rms) * g[3];
+                }
+            }
+            *reinterpret_cast<f32x4 *>(xs + xs_index<EPL>(k)) = v;
+        }
+        __syncthreads();
+    }
+
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = 0.f;
+
+    uint32_t g = 0, cg = 0;
+    for (uint32_t st = 0; st < nsteps; st++) {
+        uint32_t ng = g, ncg = cg + 1;
+        if (ncg == cpg) { ncg = 0; ng = g + 1; }
+        if (st + 1 < nsteps) {
+            if (ncg == 0) {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const uint32_t u = min(u_begin + ng * UPW + r / RPU, u_end - 1);
+                    rows[r] = row_ptr<MODE>(p, u, r % RPU);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) issue_loads<WT, U, GUARD>(nxt[r], rows[r], ncg * U, lane, p.K);
+        }
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = dot_chunk<WT>(cur[r][j], xs, cg * U + j, lane, acc[r]);
+        }
+        if (cg == cpg - 1) {
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = wave_sum(acc[r]);
+#pragma unroll
+            for (int q = 0; q < UPW; q++) {
+                const uint32_t u = u_begin + g * UPW + q;
+                // lane q finishes unit q (uniform values; spreads the stores over lanes)
+                if (lane == (uint32_t)q && u < u_end) epilogue<MODE>(p, u, acc[q * RPU], RPU == 2 ? acc[q * RPU + RPU - 1] : 0.f);
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int j = 0; j < U; j++) cur[r][j] = nxt[r][j];
+        g = ng;
+        cg = ncg;
+    }
+}
+
+// ---- host side: shape checks and the (waves per block, units per wave step, K unroll) choice ----
+struct GemvPlan {
+    int upw, u;
+    bool guard;
+    uint32_t grid, block, lds_bytes;
+};
+
+static GemvPlan plan_gemv(uint32_t NU, uint32_t K, int epl, int rpu, uint32_t n_cu)
+{
+    GemvPlan pl{};
+    const uint32_t ce = 64u * epl;
+    pl.guard = (K % ce) != 0;
+    const uint32_t kc = (K + ce - 1) / ce;
+    // K unroll: 1-KiB loads per row per step
+    pl.u = pl.guard ? 1 : (kc % 4 == 0 ? 4 : (kc % 3 == 0 ? 3 : (kc % 2 == 0 ? 2 : 1)));
+    // waves per block: prefer an exact split of the units over n_cu * wpb waves
+    uint32_t wpb = 4;
+    const uint32_t cands[] = {4, 8, 6, 5, 7};
+    bool exact = false;
+    for (uint32_t c : cands) {
+        if (NU % (n_cu * c) == 0) { wpb = c; exact = true; break; }
+    }
+    uint32_t grid = n_cu;
+    if (!exact && NU < n_cu * 4) { grid = (NU + 3) / 4; wpb = 4; }  // tiny problems: fewer blocks
+    if (grid == 0) grid = 1;
+    const uint32_t upw_total = (NU + grid * wpb - 1) / (grid * wpb);  // units per wave (max)
+    // units per step: rows_in_flight * u <= 16 loads per lane per step (x2 for the register double
+    // buffer = 128 VGPRs), and divide upw_total if we can
+    int upw = 1;
+    for (int c = 4; c >= 1; c--) {
+        if (c * rpu * pl.u <= 16 && upw_total % c == 0) { upw = c; break; }
+    }
+    pl.upw = upw;
+    pl.grid = grid;
+    pl.block = wpb * 64;
+    pl.lds_bytes = (kc * ce + 16) * 4;
+    return pl;
+}
+
+template <int WT, int MODE, int UPW, int U, bool GUARD>
+static hipError_t launch_one(const GemvParams &p, const GemvPlan &pl, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_gemv<WT, MODE, UPW, U, GUARD>), dim3(pl.grid), dim3(pl.block), pl.lds_bytes, s, p);
+    return hipGetLastError();
+}
+
+template <int WT, int MODE>
+static hipError_t dispatch_plan(const GemvParams &p, const GemvPlan &pl, hipStream_t s)
+{
+    if (pl.guard) {
+        switch (pl.upw) {
+            case 1: return launch_one<WT, MODE, 1, 1, true>(p, pl, s);
+            case 2: return launch_one<WT, MODE, 2, 1, true>(p, pl, s);
+            case 3: return launch_one<WT, MODE, 3, 1, true>(p, pl, s);
+            default: return launch_one<WT, MODE, 4, 1, true>(p, pl, s);
+        }
+    }
+#define NFAI_CASE(UPW_, U_) \
+    if (pl.upw == UPW_ && pl.u == U_) return launch_one<WT, MODE, UPW_, U_, false>(p, pl, s);
+    NFAI_CASE(1, 1) NFAI_CASE(1, 2) NFAI_CASE(1, 3) NFAI_CASE(1, 4)
+    NFAI_CASE(2, 1) NFAI_CASE(2, 2) NFAI_CASE(2, 3) NFAI_CASE(2, 4)
+    NFAI_CASE(3, 1) NFAI_CASE(3, 2) NFAI_CASE(3, 3) NFAI_CASE(3, 4)
+    NFAI_CASE(4, 1) NFAI_CASE(4, 2) NFAI_CASE(4, 3) NFAI_CASE(4, 4)
+#undef NFAI_CASE
+    return hipErrorInvalidValue;
+}
+
+template <int WT>
+static hipError_t dispatch_mode(const GemvParams &p, const GemvPlan &pl, int mode, hipStream_t s)
+{
+    switch (mode) {
+        case GEMV_PLAIN: return dispatch_plan<WT, GEMV_PLAIN>(p, pl, s);
+        case GEMV_RESIDUAL: return dispatch_plan<WT, GEMV_RESIDUAL>(p, pl, s);
+        case GEMV_QKV_ROPE: return dispatch_plan<WT, GEMV_QKV_ROPE>(p, pl, s);
+        case GEMV_GATEUP: return dispatch_plan<WT, GEMV_GATEUP>(p, pl, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_gemv(const GemvArgs &a, hipStream_t s)
+{
+    GemvParams p{};
+    const int rpu = (a.mode == GEMV_QKV_ROPE || a.mode == GEMV_GATEUP) ? 2 : 1;
+    const int epl = a.w_type == NFAI_F16 ? 8 : 4;
+    if (a.w_type != NFAI_F16 && a.w_type != NFAI_F32) return hipErrorInvalidValue;
+    if (a.K == 0 || a.K % 8 != 0) return hipErrorInvalidValue;
+    uint32_t total_rows = 0;
+    for (int i = 0; i < 3; i++) {
+        p.W[i] = reinterpret_cast<const uint8_t *>(a.W[i]);
+        total_rows += a.seg_rows[i];
+    }
+    p.seg_end[0] = a.seg_rows[0];
+    p.seg_end[1] = a.seg_rows[0] + a.seg_rows[1];
+    p.seg_end[2] = total_rows;
+    if (a.mode == GEMV_QKV_ROPE) {
+        // rotation pairs must not straddle a segment or a head
+        if ((a.seg_rows[0] | a.seg_rows[1] | a.seg_rows[2] | a.D) & 1u) return hipErrorInvalidValue;
+        p.NU = total_rows / 2;
+    } else if (a.mode == GEMV_GATEUP) {
+        if (a.seg_rows[0] != a.seg_rows[1]) return hipErrorInvalidValue;
+        p.NU = a.seg_rows[0];
+    } else {
+        p.NU = a.seg_rows[0];
+    }
+    if (p.NU == 0) return hipSuccess;
+    p.row_bytes = (uint64_t)a.K * (a.w_type == NFAI_F16 ? 2 : 4);
+    p.x = a.x;
+    p.gamma = a.gamma;
+    p.eps = a.eps;
+    p.K = a.K;
+    p.y = a.y;
+    p.res = a.res;
+    p.kc = a.kcache;
+    p.vc = a.vcache;
+    p.kv_pos_stride = a.kv_pos_stride;
+    p.kv_head_stride = a.kv_head_stride;
+    p.rope_cs = a.rope_cs;
+    p.rope_dims = a.rope_dims;
+    p.D = a.D;
+    p.pos = a.pos_dev;
+    p.kv_f16 = a.kv_type == NFAI_F16;
+    const GemvPlan pl = plan_gemv(p.NU, a.K, epl, rpu, a.n_cu);
+    p.KC = (a.K + 64 * epl - 1) / (64 * epl);
+    if (pl.lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    if (a.w_type == NFAI_F16) return dispatch_mode<NFAI_F16>(p, pl, a.mode, s);
+    return dispatch_mode<NFAI_F32>(p, pl, a.mode, s);
+}
+
+}  // namespace nfai

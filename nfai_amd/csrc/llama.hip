@@ -1,0 +1,746 @@
+// llama.hip — model level of the HIP backend: what LlamaModel (graph: LlamaModel.cs:21-68,
+// token loop :99-174) and TransformerBlock (wiring TransformerBlock.cs:31-125, op sequence
+// :127-184) do in the reference, for a contiguous range of blocks (a pipeline stage).
+//
+// Per token the fused path issues, per block, five launches (+ the slice merge of attention):
+//   [RMSNorm+Wq,Wk,Wv+RoPE+KV write] -> [attention] -> [Wo + residual]
+//   -> [RMSNorm+Wgate,Wup+SiLU*up] -> [Wdown + residual]
+// then [RMSNorm+lm_head] -> [argmax + token feedback + position advance].  Position and token
+// live in device memory, so the whole token is ONE hipGraph that is replayed unchanged for every
+// position, with no host round trip inside a greedy loop.  (The reference: 16 fence-waited
+// dispatches and two host read-back/add/upload round trips per block)
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+using namespace nfai;
+
+namespace {
+
+struct Tensor {
+    int type = -1;
+    uint64_t rows = 0, cols = 0;
+    void *ptr = nullptr;
+    bool owned = false;
+    uint64_t bytes = 0;
+};
+
+struct Layer {
+    Tensor attn_norm, wq, wk, wv, wo, ffn_norm, wgate, wup, wdown;
+    void *kcache = nullptr, *vcache = nullptr;
+};
+
+enum KClass { KC_QKV = 0, KC_ATTN = 1, KC_WO = 2, KC_GATEUP = 3, KC_DOWN = 4, KC_LMHEAD = 5, KC_OTHER = 6, KC_N = 8 };
+
+constexpr uint32_t RING_LEN = 8192;
+
+struct Model {
+    uint32_t magic = 0x4E464D44;  // 'NFMD'
+    Ctx *ctx = nullptr;
+    nfai_llama_desc d{};
+    bool finalized = false;
+    bool first_stage = false, last_stage = false;
+    bool unfused = false, use_graph = true, kv_f16 = false;
+    Tensor token_embd, output_norm, output;
+    std::vector<Layer> layers;  // index = block - layer_begin
+    uint64_t kv_pos_stride = 0, kv_head_stride = 0;
+    uint32_t kv_esz = 4;
+    // device state
+    uint32_t *d_pos = nullptr, *d_tok = nullptr, *d_ring = nullptr;
+    float *d_freqs = nullptr, *d_ropecs = nullptr;
+    void *d_argmax_part = nullptr;
+    float *d_attn_part = nullptr;
+    // activations
+    float *x = nullptr, *h = nullptr, *q = nullptr, *att = nullptr, *act = nullptr, *logits = nullptr;
+    // extra activations of the unfused 1:1 chain
+    float *xn = nullptr, *qraw = nullptr, *scores = nullptr, *wts = nullptr, *proj = nullptr, *gate = nullptr, *up = nullptr;
+    uint32_t *h_pin = nullptr;  // pinned staging for token / pos
+    uint32_t pos_host = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    // profiling
+    std::vector<hipEvent_t> ev;
+    std::vector<int> ev_class;
+    bool profiling = false;
+};
+
+Model *model_of(nfai_model_t h)
+{
+    if (!handle_live(h)) return nullptr;
+    Model *m = reinterpret_cast<Model *>(h);
+    return m->magic == 0x4E464D44 ? m : nullptr;
+}
+
+#define MODEL_OR_FAIL(m, h)                                                      \
+    Model *m = model_of(h);                                                      \
+    if (!m) return fail(NFAI_ERR_INVALID, "%s: invalid model handle", __func__); \
+    HIP_TRY(hipSetDevice(m->ctx->device))
+
+int dalloc(void **p, size_t bytes, hipStream_t s)
+{
+    const size_t padded = (bytes + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(p, padded);
+    if (e != hipSuccess) return fail(NFAI_ERR_OOM, "hipMalloc(%zu) failed: %s", padded, hipGetErrorString(e));
+    HIP_TRY(hipMemsetAsync(*p, 0, padded, s));
+    return NFAI_OK;
+}
+
+#define DALLOC(ptr, bytes)                                                          \
+    do {                                                                            \
+        int _rc = dalloc(reinterpret_cast<void **>(&(ptr)), (bytes), m->ctx->stream); \
+        if (_rc) return _rc;                                                        \
+    } while (0)
+
+Tensor *find_slot(Model *m, const char *name, bool *ignored)
+{
+    *ignored = false;
+    const std::string n(name);
+    if (n == "token_embd.weight") return &m->token_embd;
+    if (n == "output_norm.weight") return &m->output_norm;
+    if (n == "output.weight") return &m->output;
+    if (n == "rope_freqs.weight") { *ignored = true; return nullptr; }  // llama3 scaling factors: the reference ignores them (TransformerBlock.cs:33-38)
+    unsigned blk = 0;
+    char rest[64] = {0};
+    if (sscanf(name, "blk.%u.%63s", &blk, rest) == 2) {
+        if (blk < m->d.layer_begin || blk >= m->d.layer_end) { *ignored = true; return nullptr; }
+        Layer &L = m->layers[blk - m->d.layer_begin];
+        const std::string r(rest);
+        if (r == "attn_norm.weight") return &L.attn_norm;
+        if (r == "attn_q.weight") return &L.wq;
+        if (r == "attn_k.weight") return &L.wk;
+        if (r == "attn_v.weight") return &L.wv;
+        if (r == "attn_output.weight") return &L.wo;
+        if (r == "ffn_norm.weight") return &L.ffn_norm;
+        if (r == "ffn_gate.weight") return &L.wgate;
+        if (r == "ffn_up.weight") return &L.wup;
+        if (r == "ffn_down.weight") return &L.wdown;
+    }
+    return nullptr;
+}
+
+int check_shape(const char *what, const Tensor &t, uint64_t rows, uint64_t cols, bool matrix)
+{
+    if (!t.ptr) return fail(NFAI_ERR_STATE, "finalize: tensor %s was never set", what);
+    if (t.rows != rows || t.cols != cols)
+        return fail(NFAI_ERR_INVALID, "finalize: tensor %s is %llux%llu, expected %llux%llu", what, (unsigned long long)t.rows,
+                    (unsigned long long)t.cols, (unsigned long long)rows, (unsigned long long)cols);
+    if (!matrix && t.type != NFAI_F32) return fail(NFAI_ERR_UNSUPPORTED, "finalize: norm gain %s must be F32 (type %d)", what, t.type);
+    if (matrix && t.type != NFAI_F16 && t.type != NFAI_F32)
+        return fail(NFAI_ERR_UNSUPPORTED, "finalize: matrix %s has ggml type %d; kernels exist for F16/F32", what, t.type);
+    return NFAI_OK;
+}
+
+// ---- launch recording (profiling) ----------------------------------------------------------------
+struct Rec {
+    Model *m;
+    int begin(int cls)
+    {
+        if (!m->profiling) return NFAI_OK;
+        hipEvent_t a, b;
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+        m->ev.push_back(a);
+        m->ev.push_back(b);
+        m->ev_class.push_back(cls);
+        HIP_TRY(hipEventRecord(a, m->ctx->stream));
+        return NFAI_OK;
+    }
+    int end()
+    {
+        if (!m->profiling) return NFAI_OK;
+        HIP_TRY(hipEventRecord(m->ev.back(), m->ctx->stream));
+        return NFAI_OK;
+    }
+};
+
+#define K_TRY(cls, expr)                                                                                        \
+    do {                                                                                                        \
+        int _rc = rec.begin(cls);                                                                               \
+        if (_rc) return _rc;                                                                                    \
+        hipError_t _e = (expr);                                                                                 \
+        if (_e != hipSuccess)                                                                                   \
+            return fail(_e == hipErrorInvalidValue ? NFAI_ERR_INVALID : NFAI_ERR_HIP, "%s: %s failed: %s", __func__, #expr, \
+                        hipGetErrorString(_e));                                                                 \
+        _rc = rec.end();                                                                                        \
+        if (_rc) return _rc;                                                                                    \
+    } while (0)
+
+GemvArgs gemv_base(Model *m, const Tensor &w, const float *x, uint32_t K)
+{
+    GemvArgs a;
+    a.W[0] = w.ptr;
+    a.seg_rows[0] = (uint32_t)w.rows;
+    a.w_type = w.type;
+    a.x = x;
+    a.K = K;
+    a.eps = m->d.eps;
+    a.n_cu = (uint32_t)m->ctx->prop.multiProcessorCount;
+    a.pos_dev = m->d_pos;
+    return a;
+}
+
+// One block, fused path (TransformerBlock.cs:127-184 in five launches + the attention merge).
+int block_fused(Model *m, Layer &L, Rec &rec)
+{
+    const nfai_llama_desc &d = m->d;
+    hipStream_t s = m->ctx->stream;
+    {
+        GemvArgs a = gemv_base(m, L.wq, m->x, d.E);
+        a.W[1] = L.wk.ptr; a.W[2] = L.wv.ptr;
+        a.seg_rows[1] = (uint32_t)L.wk.rows; a.seg_rows[2] = (uint32_t)L.wv.rows;
+        a.gamma = static_cast<const float *>(L.attn_norm.ptr);
+        a.mode = GEMV_QKV_ROPE;
+        a.y = m->q;
+        a.kcache = L.kcache; a.vcache = L.vcache;
+        a.kv_type = m->kv_f16 ? NFAI_F16 : NFAI_F32;
+        a.kv_pos_stride = m->kv_pos_stride; a.kv_head_stride = m->kv_head_stride;
+        a.rope_cs = m->d_ropecs; a.rope_dims = d.rope_dims;
+        a.H = d.H; a.Hkv = d.Hkv; a.D = d.D;
+        K_TRY(KC_QKV, launch_gemv(a, s));
+    }
+    {
+        AttnArgs a;
+        a.q = m->q; a.kcache = L.kcache; a.vcache = L.vcache;
+        a.kv_type = m->kv_f16 ? NFAI_F16 : NFAI_F32;
+        a.kv_pos_stride = m->kv_pos_stride; a.kv_head_stride = m->kv_head_stride;
+        a.o = m->att; a.H = d.H; a.Hkv = d.Hkv; a.D = d.D; a.C = d.C;
+        a.pos_dev = m->d_pos; a.partials = m->d_attn_part;
+        a.n_cu = (uint32_t)m->ctx->prop.multiProcessorCount;
+        K_TRY(KC_ATTN, launch_attn_decode(a, s));
+    }
+    {
+        GemvArgs a = gemv_base(m, L.wo, m->att, d.H * d.D);
+        a.mode = GEMV_RESIDUAL; a.res = m->x; a.y = m->h;
+        K_TRY(KC_WO, launch_gemv(a, s));
+    }
+    {
+        GemvArgs a = gemv_base(m, L.wgate, m->h, d.E);
+        a.W[1] = L.wup.ptr; a.seg_rows[1] = (uint32_t)L.wup.rows;
+        a.gamma = static_cast<const float *>(L.ffn_norm.ptr);
+        a.mode = GEMV_GATEUP; a.y = m->act;
+        K_TRY(KC_GATEUP, launch_gemv(a, s));
+    }
+    {
+        GemvArgs a = gemv_base(m, L.wdown, m->act, d.F);
+        a.mode = GEMV_RESIDUAL; a.res = m->h; a.y = m->x;
+        K_TRY(KC_DOWN, launch_gemv(a, s));
+    }
+    return NFAI_OK;
+}
+
+// One block as the reference's 16-dispatch chain, op for op (parity mode; needs the host copy
+// of the position because the 1:1 kernels take it by value).
+int block_unfused(Model *m, Layer &L, Rec &rec)
+{
+    const nfai_llama_desc &d = m->d;
+    hipStream_t s = m->ctx->stream;
+    const uint32_t p = m->pos_host, S = p + 1, HD = d.H * d.D, KD = d.Hkv * d.D;
+    float *krow = static_cast<float *>(L.kcache) + (uint64_t)p * KD;
+    float *vrow = static_cast<float *>(L.vcache) + (uint64_t)p * KD;
+    const float *an = static_cast<const float *>(L.attn_norm.ptr), *fn = static_cast<const float *>(L.ffn_norm.ptr);
+    K_TRY(KC_OTHER, launch_rmsnorm(m->x, an, m->xn, d.E, d.eps, s));                         // :129
+    { GemvArgs a = gemv_base(m, L.wq, m->xn, d.E); a.y = m->qraw; K_TRY(KC_QKV, launch_gemv(a, s)); }   // :131
+    { GemvArgs a = gemv_base(m, L.wk, m->xn, d.E); a.y = krow; K_TRY(KC_QKV, launch_gemv(a, s)); }      // :133
+    { GemvArgs a = gemv_base(m, L.wv, m->xn, d.E); a.y = vrow; K_TRY(KC_QKV, launch_gemv(a, s)); }      // :135
+    K_TRY(KC_OTHER, launch_rope(m->qraw, m->q, m->d_freqs, d.rope_dims, d.H, d.D, p, s));    // :138
+    K_TRY(KC_OTHER, launch_rope(krow, krow, m->d_freqs, d.rope_dims, d.Hkv, d.D, p, s));     // :141
+    K_TRY(KC_ATTN, launch_attn_scores(m->q, static_cast<const float *>(L.kcache), m->scores, d.H, d.Hkv, d.D, S, s));  // :144
+    K_TRY(KC_ATTN, launch_attn_softmax(m->scores, m->wts, d.H, S, d.eps, s));                // :146
+    K_TRY(KC_ATTN, launch_attn_wsum(m->wts, static_cast<const float *>(L.vcache), m->att, d.H, d.Hkv, d.D, S, s));     // :148
+    { GemvArgs a = gemv_base(m, L.wo, m->att, HD); a.y = m->proj; K_TRY(KC_WO, launch_gemv(a, s)); }    // :150
+    K_TRY(KC_OTHER, launch_add(m->x, m->proj, m->h, d.E, s));                                // :153-158
+    K_TRY(KC_OTHER, launch_rmsnorm(m->h, fn, m->xn, d.E, d.eps, s));                         // :163
+    { GemvArgs a = gemv_base(m, L.wup, m->xn, d.E); a.y = m->up; K_TRY(KC_GATEUP, launch_gemv(a, s)); }     // :165
+    { GemvArgs a = gemv_base(m, L.wgate, m->xn, d.E); a.y = m->gate; K_TRY(KC_GATEUP, launch_gemv(a, s)); } // :167
+    K_TRY(KC_OTHER, launch_silu(m->gate, m->gate, d.F, s));                                  // :169
+    K_TRY(KC_OTHER, launch_mul(m->up, m->gate, m->act, d.F, s));                             // :171
+    { GemvArgs a = gemv_base(m, L.wdown, m->act, d.F); a.y = m->proj; K_TRY(KC_DOWN, launch_gemv(a, s)); }  // :173
+    K_TRY(KC_OTHER, launch_add(m->h, m->proj, m->x, d.E, s));                                // :176-181
+    return NFAI_OK;
+}
+
+// Everything one token needs on this stage, enqueued on the stream.  Reads token/pos from device.
+int enqueue_token(Model *m, bool with_head)
+{
+    const nfai_llama_desc &d = m->d;
+    hipStream_t s = m->ctx->stream;
+    Rec rec{m};
+    const uint32_t nfreq = (d.rope_dims < d.D ? d.rope_dims : d.D) / 2;
+    K_TRY(KC_OTHER, launch_token_begin(m->first_stage ? m->token_embd.ptr : nullptr, m->token_embd.type, m->d_tok, m->x, d.E,
+                                       m->d_freqs, m->d_ropecs, nfreq, m->d_pos, s));
+    for (Layer &L : m->layers) {
+        int rc = m->unfused ? block_unfused(m, L, rec) : block_fused(m, L, rec);
+        if (rc) return rc;
+    }
+    if (m->last_stage && with_head) {
+        const Tensor &head = m->output.ptr ? m->output : m->token_embd;  // tied when output.weight is absent (LlamaModel.cs:64-67)
+        if (m->unfused) {
+            K_TRY(KC_OTHER, launch_rmsnorm(m->x, static_cast<const float *>(m->output_norm.ptr), m->xn, d.E, d.eps, s));
+            GemvArgs a = gemv_base(m, head, m->xn, d.E);
+            a.y = m->logits;
+            K_TRY(KC_LMHEAD, launch_gemv(a, s));
+        } else {
+            GemvArgs a = gemv_base(m, head, m->x, d.E);
+            a.gamma = static_cast<const float *>(m->output_norm.ptr);
+            a.y = m->logits;
+            K_TRY(KC_LMHEAD, launch_gemv(a, s));
+        }
+        K_TRY(KC_OTHER, launch_argmax(m->logits, d.V, m->d_tok, m->d_argmax_part, m->d_pos, m->d_ring, RING_LEN, s));
+    } else {
+        K_TRY(KC_OTHER, launch_pos_advance(m->d_pos, s));
+    }
+    return NFAI_OK;
+}
+
+int ensure_graph(Model *m)
+{
+    if (m->graph_exec) return NFAI_OK;
+    hipStream_t s = m->ctx->stream;
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int rc = enqueue_token(m, true);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(s, &g);
+    if (rc) {
+        if (g) hipGraphDestroy(g);
+        return rc;
+    }
+    if (e != hipSuccess) return fail(NFAI_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    m->graph = g;
+    HIP_TRY(hipGraphInstantiate(&m->graph_exec, g, nullptr, nullptr, 0));
+    return NFAI_OK;
+}
+
+// Enqueue one whole token (graph replay when allowed).
+int run_token(Model *m)
+{
+    if (m->pos_host >= m->d.C)
+        return fail(NFAI_ERR_KV_FULL, "KV cache full: position %u == capacity %u (the reference would write out of bounds here)",
+                    m->pos_host, m->d.C);
+    const bool graphable = m->use_graph && !m->unfused && !m->profiling;
+    if (graphable) {
+        int rc = ensure_graph(m);
+        if (rc) return rc;
+        HIP_TRY(hipGraphLaunch(m->graph_exec, m->ctx->stream));
+    } else {
+        int rc = enqueue_token(m, true);
+        if (rc) return rc;
+    }
+    m->pos_host++;
+    return NFAI_OK;
+}
+
+int set_token_async(Model *m, uint32_t tok)
+{
+    // Pageable source: hipMemcpyAsync stages it before returning, so a stack value is safe.
+    HIP_TRY(hipMemcpyAsync(m->d_tok, &tok, 4, hipMemcpyHostToDevice, m->ctx->stream));
+    return NFAI_OK;
+}
+
+uint64_t tensor_bytes(const Tensor &t) { return t.ptr ? weight_row_bytes(t.type, t.cols) * t.rows : 0; }
+
+}  // namespace
+
+// ---- C ABI -----------------------------------------------------------------------------------
+NFAI_API int32_t nfai_hip_llama_create(nfai_ctx_t ch, const nfai_llama_desc *desc, nfai_model_t *out)
+{
+    Ctx *c = ctx_of(ch);
+    if (!c) return fail(NFAI_ERR_INVALID, "llama_create: invalid context handle");
+    if (!desc || !out) return fail(NFAI_ERR_INVALID, "llama_create: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const nfai_llama_desc &d = *desc;
+    NFAI_REQUIRE(d.E && d.L && d.H && d.Hkv && d.D && d.F && d.V && d.C, "llama_create: zero dimension");
+    NFAI_REQUIRE(d.H % d.Hkv == 0 && d.H / d.Hkv <= 8, "llama_create: H=%u must be a multiple (<= 8x) of Hkv=%u", d.H, d.Hkv);
+    NFAI_REQUIRE(d.D == 64 || d.D == 128, "llama_create: head_dim %u (kernels exist for 64 and 128)", d.D);
+    NFAI_REQUIRE(d.E % 8 == 0 && d.F % 8 == 0 && (d.H * d.D) % 8 == 0, "llama_create: E, F, H*D must be multiples of 8");
+    NFAI_REQUIRE(d.layer_begin < d.layer_end && d.layer_end <= d.L, "llama_create: layer range [%u,%u) outside [0,%u)", d.layer_begin,
+                 d.layer_end, d.L);
+    NFAI_REQUIRE(d.rope_dims % 2 == 0 && d.rope_dims <= d.D, "llama_create: rope_dims %u", d.rope_dims);
+    NFAI_REQUIRE(d.rope_n_freqs <= d.rope_dims / 2, "llama_create: rope_n_freqs %u > rope_dims/2", d.rope_n_freqs);
+    NFAI_REQUIRE(d.C <= 32768, "llama_create: KV capacity %u > 32768", d.C);
+    Model *m = new Model();
+    m->ctx = c;
+    m->d = d;
+    m->first_stage = d.layer_begin == 0;
+    m->last_stage = d.layer_end == d.L;
+    m->unfused = (d.flags & NFAI_LLAMA_UNFUSED) != 0;
+    m->use_graph = (d.flags & NFAI_LLAMA_NO_GRAPH) == 0;
+    m->kv_f16 = (d.flags & NFAI_LLAMA_KV_F16) != 0;
+    if (m->unfused && m->kv_f16) { delete m; return fail(NFAI_ERR_INVALID, "llama_create: the 1:1 chain keeps the reference's fp32 KV cache"); }
+    m->layers.resize(d.layer_end - d.layer_begin);
+    m->kv_esz = m->kv_f16 ? 2 : 4;
+    if (m->unfused) {  // reference layout [C][Hkv*D] (MatrixMultiplyShader.cs:59-65, :286-287)
+        m->kv_pos_stride = (uint64_t)d.Hkv * d.D;
+        m->kv_head_stride = d.D;
+    } else {           // head-major [Hkv][C][D]: each attention block streams one contiguous range
+        m->kv_pos_stride = d.D;
+        m->kv_head_stride = (uint64_t)d.C * d.D;
+    }
+    const size_t kvb = (size_t)d.C * d.Hkv * d.D * m->kv_esz;
+    for (Layer &L : m->layers) {
+        DALLOC(L.kcache, kvb);
+        DALLOC(L.vcache, kvb);
+    }
+    DALLOC(m->d_pos, 256);
+    DALLOC(m->d_tok, 256);
+    DALLOC(m->d_ring, RING_LEN * 4);
+    DALLOC(m->d_freqs, (d.D / 2 + 8) * 4);
+    DALLOC(m->d_ropecs, (d.D + 16) * 4);
+    DALLOC(m->d_argmax_part, 4096);
+    DALLOC(m->d_attn_part, attn_partials_bytes(d.H, d.Hkv, d.D));
+    DALLOC(m->x, d.E * 4);
+    DALLOC(m->h, d.E * 4);
+    DALLOC(m->q, d.H * d.D * 4);
+    DALLOC(m->att, d.H * d.D * 4);
+    DALLOC(m->act, d.F * 4);
+    if (m->last_stage) DALLOC(m->logits, (size_t)d.V * 4);
+    if (m->unfused) {
+        DALLOC(m->xn, d.E * 4);
+        DALLOC(m->qraw, d.H * d.D * 4);
+        DALLOC(m->scores, (size_t)d.H * d.C * 4);
+        DALLOC(m->wts, (size_t)d.H * d.C * 4);
+        DALLOC(m->proj, d.E * 4);
+        DALLOC(m->gate, d.F * 4);
+        DALLOC(m->up, d.F * 4);
+    }
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&m->h_pin), 4096, hipHostMallocDefault));
+    // RoPE frequency table as TransformerBlock.cs:33-38 builds it; entries >= rope_n_freqs are zero
+    // (the reference uploads 32 entries only, TransformerBlock.cs:66).
+    std::vector<float> fr(d.D / 2 + 8, 0.f);
+    for (uint32_t i = 0; i < d.rope_dims / 2; i++) {
+        const float f = 1.0f / powf(d.rope_base, (float)i / ((float)d.rope_dims / 2.0f));
+        fr[i] = i < d.rope_n_freqs ? f : 0.0f;
+    }
+    HIP_TRY(hipMemcpyAsync(m->d_freqs, fr.data(), fr.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    handle_register(m);
+    *out = reinterpret_cast<nfai_model_t>(m);
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_llama_destroy(nfai_model_t h)
+{
+    MODEL_OR_FAIL(m, h);
+    hipStreamSynchronize(m->ctx->stream);
+    if (m->graph_exec) hipGraphExecDestroy(m->graph_exec);
+    if (m->graph) hipGraphDestroy(m->graph);
+    for (hipEvent_t e : m->ev) hipEventDestroy(e);
+    auto free_t = [](Tensor &t) { if (t.owned && t.ptr) hipFree(t.ptr); };
+    free_t(m->token_embd); free_t(m->output_norm); free_t(m->output);
+    for (Layer &L : m->layers) {
+        free_t(L.attn_norm); free_t(L.wq); free_t(L.wk); free_t(L.wv); free_t(L.wo);
+        free_t(L.ffn_norm); free_t(L.wgate); free_t(L.wup); free_t(L.wdown);
+        hipFree(L.kcache); hipFree(L.vcache);
+    }
+    void *ptrs[] = {m->d_pos, m->d_tok, m->d_ring, m->d_freqs, m->d_ropecs, m->d_argmax_part, m->d_attn_part, m->x, m->h,
+                    m->q, m->att, m->act, m->logits, m->xn, m->qraw, m->scores, m->wts, m->proj, m->gate, m->up};
+    for (void *p : ptrs) if (p) hipFree(p);
+    if (m->h_pin) hipHostFree(m->h_pin);
+    m->magic = 0;
+    handle_unregister(m);
+    delete m;
+    return NFAI_OK;
+}
+
+static int set_tensor_impl(Model *m, const char *name, int type, uint64_t rows, uint64_t cols, const void *host, void *dev)
+{
+    if (!name) return fail(NFAI_ERR_INVALID, "set_tensor: null name");
+    bool ignored = false;
+    Tensor *t = find_slot(m, name, &ignored);
+    if (ignored) return NFAI_OK;
+    if (!t) return fail(NFAI_ERR_INVALID, "set_tensor: unknown tensor name '%s'", name);
+    const uint64_t rb = weight_row_bytes(type, cols);
+    if (rb == 0) return fail(NFAI_ERR_UNSUPPORTED, "set_tensor(%s): ggml type %d with %llu columns is not supported (the reference "
+                             "throws \"Unsupported data type\" for everything but F32/F16, Parser.cs:111-114)", name, type,
+                             (unsigned long long)cols);
+    if (t->owned && t->ptr) { HIP_TRY(hipFree(t->ptr)); }
+    t->type = type; t->rows = rows; t->cols = cols; t->bytes = rb * rows;
+    if (dev) {
+        if (reinterpret_cast<uintptr_t>(dev) & 15) return fail(NFAI_ERR_INVALID, "set_tensor_device(%s): pointer not 16-byte aligned", name);
+        t->ptr = dev;
+        t->owned = false;
+    } else {
+        if (!host) return fail(NFAI_ERR_INVALID, "set_tensor(%s): null data", name);
+        DALLOC(t->ptr, t->bytes);
+        t->owned = true;
+        HIP_TRY(hipMemcpyAsync(t->ptr, host, t->bytes, hipMemcpyHostToDevice, m->ctx->stream));
+        HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    }
+    m->finalized = false;
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_llama_set_tensor(nfai_model_t h, const char *name, int32_t type, uint64_t rows, uint64_t cols, const void *host)
+{
+    MODEL_OR_FAIL(m, h);
+    return set_tensor_impl(m, name, type, rows, cols, host, nullptr);
+}
+
+NFAI_API int32_t nfai_hip_llama_set_tensor_device(nfai_model_t h, const char *name, int32_t type, uint64_t rows, uint64_t cols, void *dev)
+{
+    MODEL_OR_FAIL(m, h);
+    if (!dev) return fail(NFAI_ERR_INVALID, "set_tensor_device: null pointer");
+    return set_tensor_impl(m, name, type, rows, cols, nullptr, dev);
+}
+
+NFAI_API int32_t nfai_hip_llama_finalize(nfai_model_t h)
+{
+    MODEL_OR_FAIL(m, h);
+    const nfai_llama_desc &d = m->d;
+    int rc;
+    if (m->first_stage || (m->last_stage && !m->output.ptr))
+        if ((rc = check_shape("token_embd.weight", m->token_embd, d.V, d.E, true))) return rc;
+    if (m->last_stage) {
+        if ((rc = check_shape("output_norm.weight", m->output_norm, 1, d.E, false))) return rc;
+        if (m->output.ptr && (rc = check_shape("output.weight", m->output, d.V, d.E, true))) return rc;
+    }
+    for (size_t i = 0; i < m->layers.size(); i++) {
+        Layer &L = m->layers[i];
+        char nm[64];
+#define CHK(field, suffix, r, c_, mat)                                         \
+    snprintf(nm, sizeof(nm), "blk.%zu." suffix, i + d.layer_begin);            \
+    if ((rc = check_shape(nm, L.field, r, c_, mat))) return rc;
+        CHK(attn_norm, "attn_norm.weight", 1, d.E, false)
+        CHK(wq, "attn_q.weight", d.H * d.D, d.E, true)
+        CHK(wk, "attn_k.weight", d.Hkv * d.D, d.E, true)
+        CHK(wv, "attn_v.weight", d.Hkv * d.D, d.E, true)
+        CHK(wo, "attn_output.weight", d.E, d.H * d.D, true)
+        CHK(ffn_norm, "ffn_norm.weight", 1, d.E, false)
+        CHK(wgate, "ffn_gate.weight", d.F, d.E, true)
+        CHK(wup, "ffn_up.weight", d.F, d.E, true)
+        CHK(wdown, "ffn_down.weight", d.E, d.F, true)
+#undef CHK
+        if (!m->unfused) {
+            if (L.wq.type != L.wk.type || L.wq.type != L.wv.type || L.wgate.type != L.wup.type)
+                return fail(NFAI_ERR_UNSUPPORTED, "finalize: blk.%zu mixes tensor types inside a fused group (q/k/v or gate/up)", i + d.layer_begin);
+        }
+    }
+    if (m->graph_exec) { hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    if (m->graph) { hipGraphDestroy(m->graph); m->graph = nullptr; }
+    m->finalized = true;
+    return NFAI_OK;
+}
+
+#define NEED_FINAL(m) \
+    if (!(m)->finalized) return fail(NFAI_ERR_STATE, "%s: call nfai_hip_llama_finalize first", __func__)
+
+NFAI_API int32_t nfai_hip_llama_decode_step(nfai_model_t h, uint32_t token, float *logits_host, uint32_t *argmax)
+{
+    MODEL_OR_FAIL(m, h);
+    NEED_FINAL(m);
+    if (!(m->first_stage && m->last_stage)) return fail(NFAI_ERR_STATE, "decode_step: model is a pipeline stage; use nfai_hip_llama_stage_step");
+    if (token >= m->d.V) return fail(NFAI_ERR_INVALID, "decode_step: token %u >= vocab %u", token, m->d.V);
+    int rc = set_token_async(m, token);
+    if (rc) return rc;
+    if ((rc = run_token(m))) return rc;
+    hipStream_t s = m->ctx->stream;
+    if (logits_host) HIP_TRY(hipMemcpyAsync(logits_host, m->logits, (size_t)m->d.V * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(m->h_pin, m->d_tok, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (argmax) *argmax = m->h_pin[0];
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_llama_set_token(nfai_model_t h, uint32_t token)
+{
+    MODEL_OR_FAIL(m, h);
+    if (token >= m->d.V) return fail(NFAI_ERR_INVALID, "set_token: token %u >= vocab %u", token, m->d.V);
+    return set_token_async(m, token);
+}
+
+NFAI_API int32_t nfai_hip_llama_decode_enqueue(nfai_model_t h, uint32_t n_steps)
+{
+    MODEL_OR_FAIL(m, h);
+    NEED_FINAL(m);
+    if (!(m->first_stage && m->last_stage)) return fail(NFAI_ERR_STATE, "decode_enqueue: model is a pipeline stage");
+    if (m->pos_host + n_steps > m->d.C)
+        return fail(NFAI_ERR_KV_FULL, "decode_enqueue: %u steps from position %u exceed KV capacity %u", n_steps, m->pos_host, m->d.C);
+    for (uint32_t i = 0; i < n_steps; i++) {
+        int rc = run_token(m);
+        if (rc) return rc;
+    }
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_llama_fetch_tokens(nfai_model_t h, uint32_t n, uint32_t *tokens_out)
+{
+    MODEL_OR_FAIL(m, h);
+    if (!tokens_out || n == 0 || n > RING_LEN || n > m->pos_host) return fail(NFAI_ERR_INVALID, "fetch_tokens: n=%u (pos %u, ring %u)", n, m->pos_host, RING_LEN);
+    hipStream_t s = m->ctx->stream;
+    std::vector<uint32_t> ring(RING_LEN);
+    HIP_TRY(hipMemcpyAsync(ring.data(), m->d_ring, RING_LEN * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (uint32_t i = 0; i < n; i++) tokens_out[i] = ring[(m->pos_host - n + i) % RING_LEN];
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_llama_decode_greedy(nfai_model_t h, uint32_t first_token, uint32_t n_steps, uint32_t *tokens_out)
+{
+    int rc = nfai_hip_llama_set_token(h, first_token);
+    if (rc) return rc;
+    if ((rc = nfai_hip_llama_decode_enqueue(h, n_steps))) return rc;
+    return nfai_hip_llama_fetch_tokens(h, n_steps, tokens_out);
+}
+
+NFAI_API int32_t nfai_hip_llama_prefill(nfai_model_t h, const uint32_t *tokens, uint32_t n, float *logits_last_host)
+{
+    MODEL_OR_FAIL(m, h);
+    NEED_FINAL(m);
+    if (!tokens || n == 0) return fail(NFAI_ERR_INVALID, "prefill: empty prompt");
+    // Round 1: the prompt goes through the M = 1 path token by token, exactly as the reference
+    // feeds it (LlamaModel.cs:103-126); the batched MFMA path replaces this loop.
+    for (uint32_t i = 0; i < n; i++) {
+        int rc = nfai_hip_llama_decode_step(h, tokens[i], i + 1 == n ? logits_last_host : nullptr, nullptr);
+        if (rc) return rc;
+    }
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_llama_stage_step(nfai_model_t h, uint32_t token, const void *hidden_in, void *hidden_out,
+                                           float *logits_host, uint32_t *argmax)
+{
+    MODEL_OR_FAIL(m, h);
+    NEED_FINAL(m);
+    hipStream_t s = m->ctx->stream;
+    if (m->pos_host >= m->d.C) return fail(NFAI_ERR_KV_FULL, "stage_step: KV cache full at position %u", m->pos_host);
+    if (m->first_stage) {
+        if (token >= m->d.V) return fail(NFAI_ERR_INVALID, "stage_step: token %u >= vocab %u", token, m->d.V);
+        int rc = set_token_async(m, token);
+        if (rc) return rc;
+    } else {
+        if (!hidden_in) return fail(NFAI_ERR_INVALID, "stage_step: hidden_in is required on a non-first stage");
+        HIP_TRY(hipMemcpyAsync(m->x, hidden_in, (size_t)m->d.E * 4, hipMemcpyDeviceToDevice, s));
+    }
+    int rc = enqueue_token(m, true);
+    if (rc) return rc;
+    m->pos_host++;
+    if (!m->last_stage) {
+        if (!hidden_out) return fail(NFAI_ERR_INVALID, "stage_step: hidden_out is required on a non-last stage");
+        HIP_TRY(hipMemcpyAsync(hidden_out, m->x, (size_t)m->d.E * 4, hipMemcpyDeviceToDevice, s));
+        return NFAI_OK;
+    }
+    if (logits_host || argmax) {
+        if (logits_host) HIP_TRY(hipMemcpyAsync(logits_host, m->logits, (size_t)m->d.V * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(m->h_pin, m->d_tok, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (argmax) *argmax = m->h_pin[0];
+    }
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_llama_set_pos(nfai_model_t h, uint32_t pos)
+{
+    MODEL_OR_FAIL(m, h);
+    if (pos > m->d.C) return fail(NFAI_ERR_INVALID, "set_pos: %u > capacity %u", pos, m->d.C);
+    HIP_TRY(hipMemcpyAsync(m->d_pos, &pos, 4, hipMemcpyHostToDevice, m->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    m->pos_host = pos;
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_llama_reset(nfai_model_t h) { return nfai_hip_llama_set_pos(h, 0); }
+
+NFAI_API int32_t nfai_hip_llama_pos(nfai_model_t h, uint32_t *pos)
+{
+    MODEL_OR_FAIL(m, h);
+    if (pos) *pos = m->pos_host;
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_llama_read(nfai_model_t h, int32_t which, float *host, uint64_t n)
+{
+    MODEL_OR_FAIL(m, h);
+    const nfai_llama_desc &d = m->d;
+    const float *src = nullptr;
+    uint64_t cap = 0;
+    switch (which) {
+        case 0: src = m->x; cap = d.E; break;
+        case 1: src = m->q; cap = (uint64_t)d.H * d.D; break;
+        case 2: src = m->att; cap = (uint64_t)d.H * d.D; break;
+        case 3: src = m->act; cap = d.F; break;
+        case 4: src = m->logits; cap = d.V; break;
+    }
+    if (!src || !host || n > cap) return fail(NFAI_ERR_INVALID, "llama_read: which=%d n=%llu", which, (unsigned long long)n);
+    HIP_TRY(hipMemcpyAsync(host, src, n * 4, hipMemcpyDeviceToHost, m->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_llama_read_kv(nfai_model_t h, uint32_t layer, int32_t is_v, uint32_t pos, float *host)
+{
+    MODEL_OR_FAIL(m, h);
+    const nfai_llama_desc &d = m->d;
+    if (layer < d.layer_begin || layer >= d.layer_end || pos >= d.C || !host) return fail(NFAI_ERR_INVALID, "read_kv: layer %u pos %u", layer, pos);
+    Layer &L = m->layers[layer - d.layer_begin];
+    const char *base = static_cast<const char *>(is_v ? L.vcache : L.kcache);
+    hipStream_t s = m->ctx->stream;
+    std::vector<uint16_t> tmp16;
+    if (m->kv_f16) tmp16.resize((size_t)d.Hkv * d.D);
+    for (uint32_t kh = 0; kh < d.Hkv; kh++) {
+        const uint64_t idx = (uint64_t)pos * m->kv_pos_stride + (uint64_t)kh * m->kv_head_stride;
+        void *dst = m->kv_f16 ? static_cast<void *>(tmp16.data() + (size_t)kh * d.D) : static_cast<void *>(host + (size_t)kh * d.D);
+        HIP_TRY(hipMemcpyAsync(dst, base + idx * m->kv_esz, (size_t)d.D * m->kv_esz, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    if (m->kv_f16)
+        for (size_t i = 0; i < tmp16.size(); i++) {
+            _Float16 hv;
+            memcpy(&hv, &tmp16[i], 2);
+            host[i] = (float)hv;
+        }
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_llama_bytes_per_token(nfai_model_t h, uint32_t pos, uint64_t *total, uint64_t *dominant)
+{
+    MODEL_OR_FAIL(m, h);
+    const nfai_llama_desc &d = m->d;
+    uint64_t t = 0, dom = 0;
+    for (const Layer &L : m->layers) {
+        const uint64_t qkv = tensor_bytes(L.wq) + tensor_bytes(L.wk) + tensor_bytes(L.wv);
+        const uint64_t gu = tensor_bytes(L.wgate) + tensor_bytes(L.wup);
+        t += qkv + gu + tensor_bytes(L.wo) + tensor_bytes(L.wdown);
+        // KV: read p+1 positions, write 1
+        t += 2ull * d.Hkv * d.D * m->kv_esz * ((uint64_t)pos + 1) + 2ull * d.Hkv * d.D * m->kv_esz;
+        if (gu > dom) dom = gu;
+        if (qkv > dom) dom = qkv;
+    }
+    if (m->first_stage) t += weight_row_bytes(m->token_embd.type, d.E);
+    if (m->last_stage) {
+        const Tensor &head = m->output.ptr ? m->output : m->token_embd;
+        t += tensor_bytes(head);
+    }
+    if (total) *total = t;
+    if (dominant) *dominant = dom;
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_llama_profile_step(nfai_model_t h, uint32_t token, float *ms_by_class, uint32_t *launches_by_class)
+{
+    MODEL_OR_FAIL(m, h);
+    NEED_FINAL(m);
+    if (!ms_by_class || !launches_by_class) return fail(NFAI_ERR_INVALID, "profile_step: null output");
+    if (!(m->first_stage && m->last_stage)) return fail(NFAI_ERR_STATE, "profile_step: whole-model contexts only");
+    int rc = set_token_async(m, token);
+    if (rc) return rc;
+    for (hipEvent_t e : m->ev) hipEventDestroy(e);
+    m->ev.clear();
+    m->ev_class.clear();
+    m->profiling = true;
+    rc = run_token(m);
+    m->profiling = false;
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    for (int i = 0; i < KC_N; i++) { ms_by_class[i] = 0.f; launches_by_class[i] = 0; }
+    for (size_t i = 0; i < m->ev_class.size(); i++) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, m->ev[2 * i], m->ev[2 * i + 1]));
+        ms_by_class[m->ev_class[i]] += ms;
+        launches_by_class[m->ev_class[i]]++;
+    }
+    return NFAI_OK;
+}

@@ -1,0 +1,273 @@
+"""LlamaModel / LlamaModelFactory / ModelOptions / SamplingUtils on the HIP backend.
+
+Mirrors NFAI.Models.Llama3/LlamaModel.cs, LlamaModelFactory.cs, SamplingUtils.cs and
+NFAI.Models/ModelOptions.cs.  `LlamaModel` drives the C++ model object of libnfai_hip.so
+(fused kernels, one hipGraph per token); `ChainLlamaModel` builds the same network out of the
+1:1 operator classes of `nfai_amd.shaders` exactly as the reference constructor wires them
+(LlamaModel.cs:43-67) and is the op-surface parity harness.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import call
+from .hip import HipBufferManager
+from .shaders import MatrixMultiplyShader, RMSNormShader, TokenEmbedShader, TransformerBlock
+
+_GGML = {np.dtype(np.float32): _lib.F32, np.dtype(np.float16): _lib.F16}
+
+
+@dataclass
+class ModelOptions:
+    """≙ NFAI.Models/ModelOptions.cs:3-8."""
+    GGUFPath: str = ""
+    KVCacheSize: int = 512
+
+
+@dataclass
+class QuantTensor:
+    """A GGUF tensor kept in its on-disk block encoding (Q4_K / Q6_K): raw bytes + logical shape."""
+    data: np.ndarray  # uint8
+    ggml_type: int
+    shape: tuple  # (rows, cols) = (ne1, ne0)
+
+
+def dims_from_metadata(metadata: dict, tensors: dict) -> dict:
+    """The keys LlamaModel reads (LlamaModel.cs:23-39); F and V come from tensor shapes as the
+    reference takes them from ComputeCollection.Shape (TransformerBlock.cs:47-101)."""
+    eps = next((v for k, v in metadata.items() if "epsilon" in k), 0.0)  # first key containing "epsilon" (:28)
+    H = int(metadata["llama.attention.head_count"])
+    E = int(_shape(tensors["token_embd.weight"])[1])
+    D = int(metadata.get("llama.attention.key_length", E // H))
+    return dict(
+        E=E, L=int(metadata["llama.block_count"]), H=H, Hkv=int(metadata["llama.attention.head_count_kv"]), D=D,
+        F=int(_shape(tensors["blk.0.ffn_gate.weight"])[0]), V=int(_shape(tensors["token_embd.weight"])[0]),
+        eps=float(eps), rope_dims=int(metadata.get("llama.rope.dimension_count", D)),
+        rope_base=float(metadata.get("llama.rope.freq_base", 500000.0)))
+
+
+def _shape(t):
+    return t.shape if isinstance(t, (np.ndarray, QuantTensor)) else t.shape
+
+
+class SamplingUtils:
+    """≙ SamplingUtils.cs:3-58 (host side, NumPy)."""
+
+    @staticmethod
+    def Softmax(logits: np.ndarray) -> np.ndarray:
+        e = np.exp(logits - logits.max(), dtype=np.float32)
+        return e / e.sum(dtype=np.float32)
+
+    @staticmethod
+    def TopP(values: np.ndarray, temperature: float = 0.5, topP: float = 0.95, topK: int = 40,
+             rng: np.random.Generator | None = None) -> int:
+        probs = SamplingUtils.Softmax(np.asarray(values, np.float32) / np.float32(temperature))
+        order = np.argsort(-probs, kind="stable")[:topK]
+        cum = np.cumsum(probs[order], dtype=np.float32)
+        keep = int(np.searchsorted(cum, topP, side="left")) + 1  # include the element that crosses topP
+        order = order[:keep]
+        p = probs[order] / probs[order].sum(dtype=np.float32)
+        r = (rng or np.random.default_rng()).random(dtype=np.float32)
+        running = np.cumsum(p, dtype=np.float32)
+        idx = int(np.searchsorted(running, r, side="right"))
+        return int(order[min(idx, len(order) - 1)])
+
+    @staticmethod
+    def ArgMax(values: np.ndarray) -> int:
+        return int(np.argmax(values))  # first maximum, as values.ToList().IndexOf(max) (:56)
+
+
+class LlamaModel:
+    """≙ LlamaModel (LlamaModel.cs:10-175) for blocks [layer_begin, layer_end) of the network.
+
+    tensors: dict GGUF-name -> ndarray (float16/float32) | QuantTensor | (device_ptr:int, ggml_type, rows, cols).
+    """
+
+    def __init__(self, mgr: HipBufferManager, metadata: dict, tensors: dict, contextSize: int = 1024, *,
+                 tokenizer=None, unfused: bool = False, graph: bool = True, kv_f16: bool = False,
+                 rope_n_freqs: int | None = None, rope_base: float | None = 500000.0,
+                 layer_range: tuple[int, int] | None = None, dims: dict | None = None):
+        self.mgr = mgr
+        d = dims or dims_from_metadata(metadata, tensors)
+        self.dims = d
+        self.ModelName = str(metadata.get("general.name", "unknown"))
+        self.tokenizer = tokenizer
+        self.firstInput = True
+        lb, le = layer_range or (0, d["L"])
+        flags = (_lib.LLAMA_UNFUSED if unfused else 0) | (0 if graph else _lib.LLAMA_NO_GRAPH) | (_lib.LLAMA_KV_F16 if kv_f16 else 0)
+        rd = d["rope_dims"]
+        desc = _lib.LlamaDescC(d["E"], d["L"], d["H"], d["Hkv"], d["D"], d["F"], d["V"], int(contextSize), d["eps"],
+                               # the reference ignores llama.rope.freq_base and uses 500000 (TransformerBlock.cs:33)
+                               float(rope_base if rope_base is not None else d["rope_base"]), rd,
+                               rd // 2 if rope_n_freqs is None else rope_n_freqs, lb, le, flags, 0)
+        self.C = int(contextSize)
+        h = _lib.H()
+        call("nfai_hip_llama_create", mgr.handle, C.byref(desc), C.byref(h))
+        self.handle = h
+        self._keep = []
+        for name, t in tensors.items():
+            self.SetTensor(name, t)
+        call("nfai_hip_llama_finalize", self.handle)
+
+    def SetTensor(self, name: str, t) -> None:
+        if isinstance(t, tuple):  # already resident in HBM
+            ptr, ty, rows, cols = t
+            call("nfai_hip_llama_set_tensor_device", self.handle, name.encode(), ty, rows, cols, C.c_void_p(ptr))
+            return
+        if isinstance(t, QuantTensor):
+            a, ty, (rows, cols) = np.ascontiguousarray(t.data), t.ggml_type, t.shape
+        else:
+            a = np.ascontiguousarray(t)
+            ty = _GGML[a.dtype]
+            rows, cols = (1, a.shape[0]) if a.ndim == 1 else a.shape
+        call("nfai_hip_llama_set_tensor", self.handle, name.encode(), ty, rows, cols, a.ctypes.data_as(C.c_void_p))
+
+    # -- one token (LlamaModel.cs:116-125)
+    def Step(self, token: int, want_logits: bool = True):
+        logits = np.empty(self.dims["V"], np.float32) if want_logits else None
+        am = C.c_uint32()
+        call("nfai_hip_llama_decode_step", self.handle, int(token),
+             logits.ctypes.data_as(C.POINTER(C.c_float)) if want_logits else None, C.byref(am))
+        return logits, am.value
+
+    def Greedy(self, first_token: int, n_steps: int) -> np.ndarray:
+        out = np.empty(n_steps, np.uint32)
+        call("nfai_hip_llama_decode_greedy", self.handle, int(first_token), n_steps, out.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return out
+
+    def SetToken(self, token: int) -> None:
+        call("nfai_hip_llama_set_token", self.handle, int(token))
+
+    def Enqueue(self, n_steps: int) -> None:
+        call("nfai_hip_llama_decode_enqueue", self.handle, n_steps)
+
+    def FetchTokens(self, n: int) -> np.ndarray:
+        out = np.empty(n, np.uint32)
+        call("nfai_hip_llama_fetch_tokens", self.handle, n, out.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return out
+
+    def Prefill(self, tokens, want_logits: bool = True):
+        t = np.ascontiguousarray(tokens, np.uint32)
+        logits = np.empty(self.dims["V"], np.float32) if want_logits else None
+        call("nfai_hip_llama_prefill", self.handle, t.ctypes.data_as(C.POINTER(C.c_uint32)), t.size,
+             logits.ctypes.data_as(C.POINTER(C.c_float)) if want_logits else None)
+        return logits
+
+    def StageStep(self, token: int = 0, hidden_in: int | None = None, hidden_out: int | None = None, want_logits: bool = False,
+                  want_argmax: bool = False):
+        logits = np.empty(self.dims["V"], np.float32) if want_logits else None
+        am = C.c_uint32()
+        call("nfai_hip_llama_stage_step", self.handle, int(token), C.c_void_p(hidden_in), C.c_void_p(hidden_out),
+             logits.ctypes.data_as(C.POINTER(C.c_float)) if want_logits else None, C.byref(am) if (want_argmax or want_logits) else None)
+        return logits, am.value
+
+    def Reset(self) -> None:
+        call("nfai_hip_llama_reset", self.handle)
+
+    def SetPos(self, pos: int) -> None:
+        call("nfai_hip_llama_set_pos", self.handle, int(pos))
+
+    @property
+    def Pos(self) -> int:
+        p = C.c_uint32()
+        call("nfai_hip_llama_pos", self.handle, C.byref(p))
+        return p.value
+
+    def Read(self, which: int, n: int) -> np.ndarray:
+        out = np.empty(n, np.float32)
+        call("nfai_hip_llama_read", self.handle, which, out.ctypes.data_as(C.POINTER(C.c_float)), n)
+        return out
+
+    def ReadKV(self, layer: int, is_v: bool, pos: int) -> np.ndarray:
+        out = np.empty(self.dims["Hkv"] * self.dims["D"], np.float32)
+        call("nfai_hip_llama_read_kv", self.handle, layer, int(is_v), pos, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def BytesPerToken(self, pos: int) -> tuple[int, int]:
+        t, d = C.c_uint64(), C.c_uint64()
+        call("nfai_hip_llama_bytes_per_token", self.handle, pos, C.byref(t), C.byref(d))
+        return t.value, d.value
+
+    def ProfileStep(self, token: int):
+        ms = (C.c_float * 8)()
+        n = (C.c_uint32 * 8)()
+        call("nfai_hip_llama_profile_step", self.handle, int(token), ms, n)
+        names = ["qkv", "attn", "wo", "gateup", "down", "lmhead", "other"]
+        return {k: (ms[i], n[i]) for i, k in enumerate(names)}
+
+    # -- the token loop (LlamaModel.RunAsync, :99-174)
+    def RunAsync(self, prompt: str, greedy: bool = False, max_tokens: int | None = None, rng=None):
+        if self.tokenizer is None:
+            raise RuntimeError("RunAsync needs a tokenizer (nfai_amd.tokenizer.Tokenizer(metadata))")
+        tokenIds = self.tokenizer.Tokenize(prompt, addBos=self.firstInput)
+        self.firstInput = False
+        logits = None
+        for tok in tokenIds:  # prompt, one token at a time (:103-126)
+            logits, _ = self.Step(tok)
+        pick = SamplingUtils.ArgMax if greedy else (lambda v: SamplingUtils.TopP(v, rng=rng))
+        tk = pick(logits)
+        yield self.tokenizer.Detokenize([tk])
+        n = 1
+        while tk != self.tokenizer.EosTokenId and (max_tokens is None or n < max_tokens):
+            logits, _ = self.Step(tk)
+            tk = pick(logits)
+            n += 1
+            if tk != self.tokenizer.EosTokenId:
+                yield self.tokenizer.Detokenize([tk])
+
+    def Dispose(self) -> None:  # the reference throws NotImplementedException (:70-74)
+        if self.handle is not None:
+            call("nfai_hip_llama_destroy", self.handle)
+            self.handle = None
+
+
+class LlamaModelFactory:
+    """≙ LlamaModelFactory (LlamaModelFactory.cs:7-45): the plugin hook AbstractModelFactory.TryCreate."""
+
+    def __init__(self, device: int = 0):
+        self.mgr = HipBufferManager(device)
+
+    def TryCreate(self, metadata: dict, tensors: dict, modelOptions: ModelOptions, **kw):
+        if str(metadata.get("general.architecture", "")) != "llama":
+            return False, None
+        return True, LlamaModel(self.mgr, metadata, tensors, modelOptions.KVCacheSize, **kw)
+
+    def Dispose(self) -> None:
+        self.mgr.Dispose()
+
+
+class ChainLlamaModel:
+    """The network as the reference constructor builds it out of op objects (LlamaModel.cs:43-67):
+    TokenEmbedShader -> TransformerBlock x L -> RMSNormShader -> MatrixMultiplyShader(lm_head, tied)."""
+
+    def __init__(self, mgr, metadata: dict, tensors: dict, contextSize: int = 1024, ropeTableEntries: int | None = 32):
+        d = dims_from_metadata(metadata, tensors)
+        self.dims, self.mgr = d, mgr
+        emb = tensors["token_embd.weight"]
+        self.embedShader = TokenEmbedShader(mgr, 1, emb.shape[1], emb)
+        lastProp = self.embedShader.GetOutputProperty()
+        self.transformerBlocks = []
+        for i in range(d["L"]):
+            blk = TransformerBlock(mgr, tensors, d["D"], d["H"], d["Hkv"], contextSize, d["eps"], i, d["rope_base"],
+                                   d["rope_dims"], i, ropeTableEntries)
+            self.transformerBlocks.append(blk)
+            blk.GetInputProperty().BindShaderProprty(lastProp)
+            lastProp = blk.GetOutputProperty()
+        self.outputNormLayer = RMSNormShader(mgr, d["E"], tensors["output_norm.weight"], d["eps"])
+        self.outputNormLayer.GetInputProperty().BindShaderProprty(lastProp)
+        lastProp = self.outputNormLayer.GetOutputProperty()
+        self.lmHead = MatrixMultiplyShader(mgr, 1, emb.shape[1], emb.shape[0], None)
+        self.lmHead.GetInputProperty().BindShaderProprty(lastProp)
+        self.lmHead.GetWeightProperty().BindShaderProprty(self.embedShader.GetWeightProperty())  # always tied (:64-67)
+
+    def Step(self, token: int) -> np.ndarray:
+        self.embedShader.Compute(token)
+        for blk in self.transformerBlocks:
+            blk.Compute()
+        self.outputNormLayer.Compute()
+        self.lmHead.Compute()
+        return self.lmHead.GetOutputs()

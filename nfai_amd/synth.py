@@ -78,3 +78,16 @@ def make_weights(dims: LlamaDims, seed: int = 1234, std: float = 0.02) -> dict:
 def make_tokens(dims: LlamaDims, n: int, seed: int = 99) -> np.ndarray:
     rng = np.random.Generator(np.random.PCG64(seed))
     return rng.integers(0, dims.V, size=n, dtype=np.uint32)
+
+
+def make_metadata(dims: LlamaDims, eps: float = 1e-5) -> dict:
+    """The GGUF metadata keys LlamaModel reads (LlamaModel.cs:23-39)."""
+    return {
+        "general.architecture": "llama", "general.name": dims.name, "llama.block_count": dims.L,
+        "llama.attention.head_count": dims.H, "llama.attention.head_count_kv": dims.Hkv,
+        "llama.attention.key_length": dims.D, "llama.attention.value_length": dims.D,
+        "llama.rope.dimension_count": dims.D, "llama.rope.freq_base": 500000.0,
+        "llama.attention.layer_norm_rms_epsilon": eps, "llama.embedding_length": dims.E,
+        "llama.feed_forward_length": dims.F, "llama.vocab_size": dims.V,
+        "tokenizer.ggml.bos_token_id": 1, "tokenizer.ggml.eos_token_id": 2,
+    }

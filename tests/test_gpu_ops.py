@@ -1,0 +1,362 @@
+"""GPU parity of every operator of the HIP backend against the CPU oracle, through the C ABI.
+
+Inputs are seeded; sizes are the BASELINE.json shapes where the oracle finishes in seconds
+(GEMV rows are sub-sampled for the big matrices by slicing N, never K).  Tolerances are fp32
+summation-order bounds: the HIP kernels add the same fp32 products in a different (tree) order.
+"""
+import numpy as np
+import pytest
+
+import oracle as orc
+from oracle import np_oracle as npo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mgr():
+    from nfai_amd.hip import HipBufferManager
+    m = HipBufferManager(0)
+    yield m
+    m.Dispose()
+
+
+def rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def gemv_tol(W, x):
+    """|sum_k fl(w*x)| reordering bound: a few ulp of sum |w||x| times log-ish factor."""
+    s = np.abs(W.astype(np.float64)) @ np.abs(x.astype(np.float64))
+    return 4e-7 * np.sqrt(W.shape[1] / 64.0) * s + 1e-7
+
+
+def test_device_is_gfx950(mgr):
+    assert mgr.info.arch.decode().startswith("gfx950")
+    assert mgr.info.wavefront_size == 64
+
+
+# ---- MatrixMultiplyShader -------------------------------------------------------------------
+@pytest.mark.parametrize("N,K", [
+    (2048, 2048), (512, 2048), (3072, 3072), (1024, 3072), (1000, 8192),   # 1B / 3B layer shapes (N sub-sampled where large)
+    (1024, 4096), (512, 14336),                                            # 8B
+    (7, 256), (33, 264), (1, 8), (130, 1000), (257, 520),                  # ragged: K not a multiple of 512, tiny N
+])
+def test_gemv_f16(mgr, N, K):
+    from nfai_amd.shaders import MatrixMultiplyShader
+    r = rng(N * 131 + K)
+    W = (0.02 * r.standard_normal((N, K))).astype(np.float16)
+    x = r.standard_normal(K).astype(np.float32)
+    op = MatrixMultiplyShader(mgr, 1, K, N, W)
+    op.GetInputProperty().SetValue(x)
+    op.Compute()
+    y = op.GetOutputs()
+    ref = orc.gemv_f16w(W, x)
+    assert (np.abs(y - ref) <= gemv_tol(W, x)).all(), np.abs(y - ref).max()
+
+
+def test_gemv_f32_weights(mgr):
+    from nfai_amd.shaders import MatrixMultiplyShader
+    r = rng(5)
+    W = r.standard_normal((300, 768)).astype(np.float32)
+    x = r.standard_normal(768).astype(np.float32)
+    op = MatrixMultiplyShader(mgr, 1, 768, 300, W)
+    op.GetInputProperty().SetValue(x)
+    op.Compute()
+    assert (np.abs(op.GetOutputs() - orc.gemv(W, x)) <= gemv_tol(W, x)).all()
+
+
+def test_gemv_lm_head_full_size(mgr):
+    """128256 x 3072 fp16 (788 MB): every row against the oracle, plus linearity y(a+b) = y(a)+y(b)."""
+    from nfai_amd.shaders import MatrixMultiplyShader
+    r = rng(77)
+    N, K = 128256, 3072
+    W = (0.02 * r.standard_normal((N, K), dtype=np.float32)).astype(np.float16)
+    a = r.standard_normal(K).astype(np.float32)
+    b = r.standard_normal(K).astype(np.float32)
+    op = MatrixMultiplyShader(mgr, 1, K, N, W)
+    outs = []
+    for v in (a, b, a + b):
+        op.GetInputProperty().SetValue(v)
+        op.Compute()
+        outs.append(op.GetOutputs())
+    ref = orc.gemv_f16w(W, a)
+    assert (np.abs(outs[0] - ref) <= gemv_tol(W, a)).all()
+    np.testing.assert_allclose(outs[2], outs[0] + outs[1], rtol=0, atol=2e-5)
+
+
+def test_gemv_cached_rows_and_overflow(mgr):
+    """The KV-cached variant writes row currentCacheSize and advances (MatrixMultiplyShader.cs:247-252,
+    :286-287); past the capacity the reference writes out of bounds, this backend raises."""
+    from nfai_amd.shaders import MatrixMultiplyShader
+    from nfai_amd._lib import KVCacheFull
+    r = rng(9)
+    W = (0.05 * r.standard_normal((64, 256))).astype(np.float16)
+    op = MatrixMultiplyShader(mgr, 1, 256, 64, W, contextSize=3)
+    rows = []
+    for i in range(3):
+        x = r.standard_normal(256).astype(np.float32)
+        op.GetInputProperty().SetValue(x)
+        op.Compute()
+        rows.append(orc.gemv_f16w(W, x))
+    got = op.GetOutputs().reshape(3, 64)
+    np.testing.assert_allclose(got, np.stack(rows), rtol=0, atol=1e-5)
+    with pytest.raises(KVCacheFull):
+        op.Compute()
+
+
+# ---- small ops ------------------------------------------------------------------------------
+@pytest.mark.parametrize("E", [256, 2048, 3072, 4096, 1000])
+def test_rmsnorm(mgr, E):
+    from nfai_amd.shaders import RMSNormShader
+    r = rng(E)
+    x = r.standard_normal(E).astype(np.float32) * 3
+    g = (1 + 0.1 * r.standard_normal(E)).astype(np.float32)
+    op = RMSNormShader(mgr, E, g, 1e-5)
+    op.GetInputProperty().SetValue(x)
+    op.Compute()
+    np.testing.assert_allclose(op.GetOutputs(), orc.rmsnorm(x, g, 1e-5), rtol=3e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("H,D,pos", [(32, 64, 0), (32, 64, 1), (24, 128, 17), (24, 128, 639), (8, 128, 511)])
+@pytest.mark.parametrize("nfreq", [None, 32])
+def test_rope(mgr, H, D, pos, nfreq):
+    from nfai_amd.shaders import RoPEShader
+    r = rng(H * D + pos)
+    x = r.standard_normal(H * D).astype(np.float32)
+    freqs = orc.rope_freqs(D, 500000.0, nfreq)
+    table = freqs if nfreq is None else freqs[:nfreq]  # the reference uploads 32 entries (TransformerBlock.cs:66)
+    op = RoPEShader(mgr, H * D, H * D, table, D, H)
+    op.GetInputProperty().SetValue(x)
+    op.Compute(pos)
+    want = orc.rope(x, freqs, D, H, D, pos)
+    # device sinf/cosf vs libm at |theta| up to 639 rad: a few ulp of the angle
+    np.testing.assert_allclose(op.GetOutputs(), want, rtol=0, atol=2e-6 * (1 + pos / 8))
+    if nfreq == 32 and D == 128:  # reference defect reproduced on request: dims 64..127 not rotated
+        got = op.GetOutputs().reshape(H, D)
+        np.testing.assert_array_equal(got[:, 64:], x.reshape(H, D)[:, 64:])
+
+
+def test_rope_in_place_on_cache_row(mgr):
+    from nfai_amd.shaders import RoPEShader
+    r = rng(3)
+    Hkv, D, C, pos = 8, 64, 16, 5
+    cache = r.standard_normal(C * Hkv * D).astype(np.float32)
+    op = RoPEShader(mgr, C * Hkv * D, C * Hkv * D, orc.rope_freqs(D), D, Hkv, C)
+    op.GetOutputProperty().BindShaderProprty(op.GetInputProperty())
+    op.GetInputProperty().SetValue(cache)
+    op.Compute(pos)
+    got = op.GetInputProperty().GetValue().reshape(C, Hkv * D)
+    want = cache.reshape(C, Hkv * D).copy()
+    want[pos] = orc.rope(want[pos], orc.rope_freqs(D), D, Hkv, D, pos)
+    np.testing.assert_allclose(got, want, rtol=0, atol=3e-6)
+    np.testing.assert_array_equal(np.delete(got, pos, 0), np.delete(want, pos, 0))  # other rows untouched
+
+
+@pytest.mark.parametrize("H,Hkv,D,S,C", [(32, 8, 64, 1, 8), (32, 8, 64, 130, 256), (24, 8, 128, 77, 128), (24, 8, 128, 640, 640)])
+def test_attention_three_stage_chain(mgr, H, Hkv, D, S, C):
+    from nfai_amd.shaders import (AttentionScoreCalculationShader, AttentionSoftmaxShader,
+                                  AttentionWeightedValueSumShader)
+    r = rng(H + S)
+    q = r.standard_normal(H * D).astype(np.float32)
+    Kc = r.standard_normal((C, Hkv * D)).astype(np.float32)
+    Vc = r.standard_normal((C, Hkv * D)).astype(np.float32)
+    sc = AttentionScoreCalculationShader(mgr, H, Hkv, C, D)
+    sm = AttentionSoftmaxShader(mgr, H, C, D, 1e-5)
+    ws = AttentionWeightedValueSumShader(mgr, H, Hkv, C, D)
+    sm.GetInputProperty().BindShaderProprty(sc.GetAttentionScoresProperty())
+    ws.GetAttentionWeights().BindShaderProprty(sm.GetAttentionWeightsProperty())
+    sc.GetQueryVectorsProperty().SetValue(q)
+    sc.GetKeyCacheProperty().SetValue(Kc)
+    ws.GetValueCache().SetValue(Vc)
+    sc.ComputeAttention(S)
+    s_ref = orc.attn_scores(q, Kc, H, Hkv, D, S)
+    got_s = sc.GetAttentionScoresProperty().GetValue()[:H * S].reshape(H, S)  # packed with stride S (:204)
+    np.testing.assert_allclose(got_s, s_ref, rtol=0, atol=2e-5)
+    sm.ComputeSoftmax(S)
+    w_ref = orc.attn_softmax(s_ref)
+    np.testing.assert_allclose(sm.GetAttentionWeightsProperty().GetValue()[:H * S].reshape(H, S), w_ref, rtol=2e-5, atol=1e-8)
+    ws.ComputeWeightedSum(S)
+    o_ref = orc.attn_wsum(w_ref, Vc, H, Hkv, D, S)
+    np.testing.assert_allclose(ws.GetAttentionOutputProperty().GetValue(), o_ref, rtol=0, atol=2e-5)
+
+
+def test_silu_mul_add_embed_argmax(mgr):
+    import ctypes as C
+    from nfai_amd._lib import call
+    from nfai_amd.hip import ShaderProperty
+    from nfai_amd.shaders import SiLUShader, ElementWiseMultiplicationShader, TokenEmbedShader
+    r = rng(21)
+    n = 8192
+    a = (4 * r.standard_normal(n)).astype(np.float32)
+    b = r.standard_normal(n).astype(np.float32)
+    s = SiLUShader(mgr, n)
+    s.GetInputProperty().SetValue(a)
+    s.Compute()
+    np.testing.assert_allclose(s.GetOutputProperty().GetValue(), orc.silu(a), rtol=3e-6, atol=1e-7)
+    m = ElementWiseMultiplicationShader(mgr, n)
+    m.GetInputA().SetValue(a)
+    m.GetInputB().SetValue(b)
+    m.Compute()
+    np.testing.assert_array_equal(m.GetOutputProperty().GetValue(), orc.mul(a, b))
+    pa, pb, py = (ShaderProperty(mgr, n) for _ in range(3))
+    pa.SetValue(a)
+    pb.SetValue(b)
+    call("nfai_hip_add", mgr.handle, pa.handle, pb.handle, py.handle, n)
+    np.testing.assert_array_equal(py.GetValue(), orc.add(a, b))
+    emb = (r.standard_normal((1000, 256))).astype(np.float16)
+    e = TokenEmbedShader(mgr, 1, 256, emb)
+    e.Compute(999)
+    np.testing.assert_array_equal(e.GetOutputs(), emb[999].astype(np.float32))
+    # argmax: first maximum wins (SamplingUtils.cs:56), also with duplicates spread over blocks
+    v = r.standard_normal(128256).astype(np.float32)
+    v[[77, 90001, 128255]] = 9.5
+    pv, pi = ShaderProperty(mgr, v.size), ShaderProperty(mgr, 1, np.uint32)
+    for _ in range(3):  # the device ticket must re-arm between launches
+        pv.SetValue(v)
+        call("nfai_hip_argmax", mgr.handle, pv.handle, v.size, pi.handle)
+        assert int(pi.GetValue()[0]) == 77 == orc.argmax(v)
+    v[3] = 11.0
+    pv.SetValue(v)
+    call("nfai_hip_argmax", mgr.handle, pv.handle, v.size, pi.handle)
+    assert int(pi.GetValue()[0]) == 3
+
+
+# ---- fused operators vs the unfused oracle chain, each at its own scale ----------------------
+@pytest.mark.parametrize("H,Hkv,D,S,C", [(32, 8, 64, 1, 64), (32, 8, 64, 15, 64), (32, 8, 64, 16, 64), (32, 8, 64, 17, 64),
+                                         (32, 8, 64, 1024, 1024), (24, 8, 128, 5, 640), (24, 8, 128, 513, 640),
+                                         (24, 8, 128, 640, 640), (32, 8, 128, 300, 4096), (4, 2, 64, 33, 40), (8, 8, 128, 100, 128)])
+@pytest.mark.parametrize("kv16", [False, True])
+def test_attn_decode_fused(mgr, H, Hkv, D, S, C, kv16):
+    import ctypes as Cc
+    from nfai_amd import _lib
+    from nfai_amd._lib import call
+    from nfai_amd.hip import ShaderProperty
+    r = rng(H * 7 + S)
+    q = r.standard_normal(H * D).astype(np.float32)
+    Kc = r.standard_normal((C, Hkv * D)).astype(np.float32)
+    Vc = r.standard_normal((C, Hkv * D)).astype(np.float32)
+    if kv16:
+        Kc, Vc = Kc.astype(np.float16), Vc.astype(np.float16)
+    dt = np.float16 if kv16 else np.float32
+    pq, po = ShaderProperty(mgr, H * D), ShaderProperty(mgr, H * D)
+    pk, pv = ShaderProperty(mgr, C * Hkv * D, dt), ShaderProperty(mgr, C * Hkv * D, dt)
+    pq.SetValue(q); pk.SetValue(Kc); pv.SetValue(Vc)
+    call("nfai_hip_attn_decode", mgr.handle, pq.handle, pk.handle, pv.handle, po.handle, H, Hkv, D, S, C,
+         _lib.F16 if kv16 else _lib.F32)
+    K32, V32 = Kc.astype(np.float32), Vc.astype(np.float32)
+    ref = orc.attn_wsum(orc.attn_softmax(orc.attn_scores(q, K32, H, Hkv, D, S)), V32, H, Hkv, D, S)
+    np.testing.assert_allclose(po.GetValue(), ref, rtol=0, atol=3e-5)
+    np.testing.assert_allclose(po.GetValue(), npo.attention(q, K32, V32, H, Hkv, D, S), rtol=0, atol=3e-5)
+
+
+def test_attn_decode_online_softmax_spike(mgr):
+    """Slice merge under a forced max jump: one key dominates inside a late slice (guide rule 26)."""
+    from nfai_amd import _lib
+    from nfai_amd._lib import call
+    from nfai_amd.hip import ShaderProperty
+    H, Hkv, D, S, C = 24, 8, 128, 600, 640
+    r = rng(4)
+    q = r.standard_normal(H * D).astype(np.float32)
+    Kc = (0.1 * r.standard_normal((C, Hkv * D))).astype(np.float32)
+    Vc = r.standard_normal((C, Hkv * D)).astype(np.float32)
+    Kc[555, :D] = 3.0 * q[:D]  # head 0's key at t=555 aligned with q -> score >> others
+    pq, po = ShaderProperty(mgr, H * D), ShaderProperty(mgr, H * D)
+    pk, pv = ShaderProperty(mgr, C * Hkv * D), ShaderProperty(mgr, C * Hkv * D)
+    pq.SetValue(q); pk.SetValue(Kc); pv.SetValue(Vc)
+    call("nfai_hip_attn_decode", mgr.handle, pq.handle, pk.handle, pv.handle, po.handle, H, Hkv, D, S, C, _lib.F32)
+    ref = orc.attn_wsum(orc.attn_softmax(orc.attn_scores(q, Kc, H, Hkv, D, S)), Vc, H, Hkv, D, S)
+    np.testing.assert_allclose(po.GetValue(), ref, rtol=0, atol=3e-5)
+    np.testing.assert_allclose(po.GetValue()[:D], Vc[555, :D], rtol=0, atol=1e-3)  # head 0 ~ one-hot on t=555
+
+
+@pytest.mark.parametrize("E,N", [(2048, 2048), (3072, 3072), (4096, 1024), (256, 96)])
+def test_gemv_fused_norm_residual(mgr, E, N):
+    from nfai_amd import _lib
+    from nfai_amd._lib import call
+    from nfai_amd.hip import ShaderProperty
+    r = rng(E + N)
+    W = (0.02 * r.standard_normal((N, E))).astype(np.float16)
+    x = r.standard_normal(E).astype(np.float32)
+    g = (1 + 0.1 * r.standard_normal(E)).astype(np.float32)
+    res = r.standard_normal(N).astype(np.float32)
+    pw = mgr.UploadWeight(_lib.F16, W, N, E)
+    px, pg, pr, py = ShaderProperty(mgr, E), ShaderProperty(mgr, E), ShaderProperty(mgr, N), ShaderProperty(mgr, N)
+    px.SetValue(x); pg.SetValue(g); pr.SetValue(res)
+    xn = orc.rmsnorm(x, g, 1e-5)
+    for gamma, resid, want in ((pg, pr, orc.add(res, orc.gemv_f16w(W, xn))), (pg, None, orc.gemv_f16w(W, xn)),
+                               (None, pr, orc.add(res, orc.gemv_f16w(W, x)))):
+        call("nfai_hip_gemv_fused", mgr.handle, pw.handle, _lib.F16, px.handle, gamma.handle if gamma else 0, 1e-5,
+             resid.handle if resid else 0, py.handle, N, E)
+        assert (np.abs(py.GetValue() - want) <= gemv_tol(W, xn if gamma else x) + 1e-6).all()
+
+
+@pytest.mark.parametrize("E,F", [(2048, 8192), (3072, 8192), (4096, 14336), (256, 520)])
+def test_gemv_gateup_silu(mgr, E, F):
+    from nfai_amd import _lib
+    from nfai_amd._lib import call
+    from nfai_amd.hip import ShaderProperty
+    r = rng(E + F)
+    Wg = (0.02 * r.standard_normal((F, E))).astype(np.float16)
+    Wu = (0.02 * r.standard_normal((F, E))).astype(np.float16)
+    x = r.standard_normal(E).astype(np.float32)
+    g = (1 + 0.1 * r.standard_normal(E)).astype(np.float32)
+    pg_, pu = mgr.UploadWeight(_lib.F16, Wg, F, E), mgr.UploadWeight(_lib.F16, Wu, F, E)
+    px, pg, py = ShaderProperty(mgr, E), ShaderProperty(mgr, E), ShaderProperty(mgr, F)
+    px.SetValue(x); pg.SetValue(g)
+    call("nfai_hip_gemv_gateup_silu", mgr.handle, pg_.handle, pu.handle, _lib.F16, px.handle, pg.handle, 1e-5, py.handle, F, E)
+    xn = orc.rmsnorm(x, g, 1e-5)
+    want = orc.mul(orc.gemv_f16w(Wu, xn), orc.silu(orc.gemv_f16w(Wg, xn)))
+    np.testing.assert_allclose(py.GetValue(), want, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("E,H,Hkv,D,C,pos,nfreq", [(2048, 32, 8, 64, 64, 0, None), (2048, 32, 8, 64, 64, 63, None),
+                                                   (3072, 24, 8, 128, 640, 511, None), (3072, 24, 8, 128, 640, 100, 32),
+                                                   (4096, 32, 8, 128, 32, 7, None), (256, 4, 2, 64, 16, 3, None)])
+@pytest.mark.parametrize("kv16", [False, True])
+def test_gemv_qkv_rope_kvwrite(mgr, E, H, Hkv, D, C, pos, nfreq, kv16):
+    from nfai_amd import _lib
+    from nfai_amd._lib import call
+    from nfai_amd.hip import ShaderProperty
+    r = rng(E + pos)
+    Wq = (0.02 * r.standard_normal((H * D, E))).astype(np.float16)
+    Wk = (0.02 * r.standard_normal((Hkv * D, E))).astype(np.float16)
+    Wv = (0.02 * r.standard_normal((Hkv * D, E))).astype(np.float16)
+    x = r.standard_normal(E).astype(np.float32)
+    g = (1 + 0.1 * r.standard_normal(E)).astype(np.float32)
+    freqs = orc.rope_freqs(D, 500000.0, nfreq)
+    dt = np.float16 if kv16 else np.float32
+    pwq, pwk, pwv = (mgr.UploadWeight(_lib.F16, w, w.shape[0], E) for w in (Wq, Wk, Wv))
+    px, pg, pf, pq = ShaderProperty(mgr, E), ShaderProperty(mgr, E), ShaderProperty(mgr, D // 2), ShaderProperty(mgr, H * D)
+    pk, pv = ShaderProperty(mgr, C * Hkv * D, dt), ShaderProperty(mgr, C * Hkv * D, dt)
+    sentinel = np.full(C * Hkv * D, 7.0, dt)
+    px.SetValue(x); pg.SetValue(g); pf.SetValue(freqs); pk.SetValue(sentinel); pv.SetValue(sentinel)
+    call("nfai_hip_gemv_qkv_rope", mgr.handle, pwq.handle, pwk.handle, pwv.handle, _lib.F16, px.handle, pg.handle, 1e-5,
+         pf.handle, D, pq.handle, pk.handle, pv.handle, H, Hkv, D, pos, _lib.F16 if kv16 else _lib.F32, E)
+    xn = orc.rmsnorm(x, g, 1e-5)
+    q_ref = orc.rope(orc.gemv_f16w(Wq, xn), freqs, D, H, D, pos)
+    k_ref = orc.rope(orc.gemv_f16w(Wk, xn), freqs, D, Hkv, D, pos)
+    v_ref = orc.gemv_f16w(Wv, xn)
+    tol = 2e-5 + 2e-6 * pos / 8
+    np.testing.assert_allclose(pq.GetValue(), q_ref, rtol=0, atol=tol)
+    Kg = pk.GetValue().reshape(C, Hkv * D).astype(np.float32)
+    Vg = pv.GetValue().reshape(C, Hkv * D).astype(np.float32)
+    kv_tol = tol + (2e-3 if kv16 else 0)
+    np.testing.assert_allclose(Kg[pos], k_ref, rtol=0, atol=kv_tol)
+    np.testing.assert_allclose(Vg[pos], v_ref, rtol=0, atol=kv_tol)
+    assert (np.delete(Kg, pos, 0) == 7.0).all() and (np.delete(Vg, pos, 0) == 7.0).all()  # only row `pos` written
+
+
+def test_error_paths(mgr):
+    from nfai_amd import _lib
+    from nfai_amd._lib import NfaiHipError, call
+    from nfai_amd.hip import ShaderProperty
+    a, b = ShaderProperty(mgr, 16), ShaderProperty(mgr, 8)
+    with pytest.raises(NfaiHipError) as e:
+        call("nfai_hip_add", mgr.handle, a.handle, b.handle, a.handle, 16)  # b too small
+    assert e.value.code == _lib.ERR_INVALID and "needs" in str(e.value)
+    with pytest.raises(NfaiHipError):
+        call("nfai_hip_silu", mgr.handle, 12345, a.handle, 16)  # bogus handle
+    with pytest.raises(NfaiHipError) as e:
+        mgr.UploadWeight(_lib.Q4_K, np.zeros(100, np.uint8), 1, 100)  # K-quants need K % 256 == 0
+    assert e.value.code == _lib.ERR_UNSUPPORTED
