@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py — decode tokens/s of the HIP Llama-3 path on MI355X, with roofline and CPU baseline.
+
+    python bench.py --gpus 1 --steps 128 --warmup 8            (default: N=1, finishes in minutes)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json metric "decode tokens/sec Llama-3.2-3B batch=1"): Llama-3.2-3B, fp16 GGUF
+weights kept fp16 in HBM, fp32 activations and fp32 KV cache (the reference's precision), batch-1
+greedy decode of `steps` tokens after a 512-token context (positions 512..512+steps-1), synthetic
+random-init weights generated directly in HBM (no checkpoints offline).  A "step" = one token
+through all 28 blocks + lm_head + argmax, token fed back on the device, one hipGraph replay.
+
+N > 1: the blocks are sharded as a layer pipeline (one contiguous range per rank, hidden state
+handed over with RCCL send/recv); N independent sequences are kept in flight so every stage is
+busy; value = tokens of all sequences / time ("weak": per-GPU bytes per step are constant).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling 6290
+CONTEXT = 512
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--model", default="llama-3.2-3b")
+    ap.add_argument("--context", type=int, default=CONTEXT)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tokens", type=int, default=0, help="tokens of the CPU baseline sample (0 = auto)")
+    ap.add_argument("--kv-f16", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=6)
+    return ap.parse_args()
+
+
+def gen_weights_hbm(torch, dims, layer_range, first, last, seed=1234):
+    """Random-init weights of the architecture, generated on the GPU, fp16 matrices / fp32 gains
+    (same distribution as nfai_amd.synth.make_weights; torch's generator instead of NumPy's)."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    out = {}
+    lb, le = layer_range
+    for name, shape in dims.shapes().items():
+        if name.startswith("blk."):
+            l = int(name.split(".")[1])
+            if not (lb <= l < le):
+                continue
+        elif name == "token_embd.weight":
+            if not (first or (last and dims.tied)):
+                continue
+        elif not last:
+            continue
+        if len(shape) == 1:
+            t = 1.0 + 0.1 * torch.randn(shape, device="cuda", dtype=torch.float32, generator=g)
+        else:
+            t = torch.empty(shape, device="cuda", dtype=torch.float16)
+            rows = max(1, (1 << 26) // shape[1])
+            for r0 in range(0, shape[0], rows):
+                r1 = min(shape[0], r0 + rows)
+                t[r0:r1] = (0.02 * torch.randn((r1 - r0, shape[1]), device="cuda", dtype=torch.float32, generator=g)).half()
+        out[name] = t
+    torch.cuda.synchronize()
+    return out
+
+
+def as_model_tensors(_lib, weights):
+    return {k: (t.data_ptr(), _lib.F16 if t.dtype.itemsize == 2 else _lib.F32,
+                1 if t.dim() == 1 else t.shape[0], t.shape[-1]) for k, t in weights.items()}
+
+
+def cpu_baseline(args, dims, weights, first_token, gpu_logits0, n_tokens):
+    """The oracle (a port of the reference path: fp32 math, reference summation order, OpenMP over
+    output rows) timed on this box's host cores on a bounded sample of the SAME workload: the
+    first `n_tokens` tokens of the same model from position 0 (weights identical to the GPU's)."""
+    import oracle as orc
+    host = {k: t.cpu().numpy() for k, t in weights.items()}
+    C = n_tokens + 1
+    desc = orc.LlamaDesc(E=dims.E, L=dims.L, H=dims.H, Hkv=dims.Hkv, D=dims.D, F=dims.F, V=dims.V, C=C)
+    ref = orc.OracleLlama(desc, host)
+    tok = first_token
+    t0 = time.perf_counter()
+    first_logits = None
+    for i in range(n_tokens):
+        lg = ref.step(tok)
+        if i == 0:
+            first_logits = lg
+        tok = orc.argmax(lg)
+    dt = time.perf_counter() - t0
+    err = float(np.abs(first_logits - gpu_logits0).max()) if gpu_logits0 is not None else None
+    return {"value": n_tokens / dt, "unit": "tokens/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": f"first {n_tokens} greedy tokens of the same model from position 0 (oracle/nfai_oracle.c, fp32 math, "
+                      f"{orc.num_threads()} OpenMP threads)",
+            "seconds": dt, "max_abs_logit_diff_vs_gpu_token0": err}
+
+
+def run_single(args):
+    import torch
+    from nfai_amd import _lib, synth
+    from nfai_amd.hip import HipBufferManager
+    from nfai_amd.llama_model import LlamaModel
+
+    dims = synth.BY_NAME[args.model]
+    torch.cuda.set_device(0)
+    weights = gen_weights_hbm(torch, dims, (0, dims.L), True, True)
+    mgr = HipBufferManager(0)
+    C = args.context + args.warmup + args.steps
+    m = LlamaModel(mgr, synth.make_metadata(dims), as_model_tensors(_lib, weights), C,
+                   graph=not args.no_graph, kv_f16=args.kv_f16, dims=dict(
+                       E=dims.E, L=dims.L, H=dims.H, Hkv=dims.Hkv, D=dims.D, F=dims.F, V=dims.V, eps=1e-5,
+                       rope_dims=dims.D, rope_base=500000.0))
+    first_token = 128000 % dims.V
+    # token 0 with logits (parity side-check against the CPU baseline), then fill the context
+    logits0, tok = m.Step(first_token)
+    m.SetToken(tok)
+    m.Enqueue(args.context - 1)
+    mgr.Synchronize()
+    # ---- warmup, then the timed region: exactly `steps` graph replays, events on the launch stream
+    m.Enqueue(args.warmup)
+    mgr.Synchronize()
+    torch.cuda.synchronize()
+    pos0 = m.Pos
+    t0 = time.perf_counter()
+    mgr.TimerBegin()
+    m.Enqueue(args.steps)
+    ev_ms = mgr.TimerEnd()
+    mgr.Synchronize()
+    wall = time.perf_counter() - t0
+    toks = m.FetchTokens(args.steps)
+    ms_per_step = ev_ms / args.steps
+    value = args.steps / (ev_ms / 1e3)
+    # ---- roofline: dominant kernel = the fused RMSNorm + Wgate/Wup GEMV + SiLU*up launch
+    pos_mid = pos0 + args.steps // 2
+    b_tok, dom_bytes = m.BytesPerToken(pos_mid)
+    prof = {}
+    for _ in range(args.profile_steps):
+        if m.Pos >= C:
+            m.SetPos(pos0)
+        for k, (ms, n) in m.ProfileStep(int(toks[-1])).items():
+            a = prof.setdefault(k, [0.0, 0])
+            a[0] += ms
+            a[1] += n
+    gu_ms = prof["gateup"][0] / max(1, prof["gateup"][1]) if prof else float("nan")
+    achieved = dom_bytes / (gu_ms * 1e-3) / 1e9
+    per_kernel_us = {k: round(1e3 * v[0] / v[1], 3) for k, v in prof.items() if v[1]}
+    out = {
+        "metric": "decode tokens/sec Llama-3.2-3B batch=1; achieved HBM GB/s vs roofline",
+        "value": value, "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{dims.name} fp16-GGUF weights (fp16 in HBM), fp32 activations + {'fp16' if args.kv_f16 else 'fp32'} KV, "
+                               f"batch-1 greedy decode of {args.steps} tokens after a {args.context}-token context",
+                   "positions": [pos0, pos0 + args.steps - 1], "kv_capacity": C, "parallelism": "single",
+                   "graph": not args.no_graph},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "kernel": "k_gemv<F16,GATEUP> (RMSNorm + Wgate/Wup GEMV + SiLU*up)",
+                     "bytes_per_launch": dom_bytes, "us_per_launch": gu_ms * 1e3},
+        "token_hbm_gbps": b_tok / (ms_per_step * 1e-3) / 1e9,
+        "token_hbm_frac_of_peak": b_tok / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        "bytes_per_token": b_tok,
+        "kernel_us_eager_events": per_kernel_us,
+        "host_wall_ms_per_step": 1e3 * wall / args.steps,
+    }
+    if not args.no_cpu_baseline:
+        n = args.cpu_tokens or 12
+        out["cpu_baseline"] = cpu_baseline(args, dims, weights, first_token, logits0, n)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        from nfai_amd.pipeline import run_bench_pipeline
+        run_bench_pipeline(args)
+    else:
+        run_single(args)
+
+
+if __name__ == "__main__":
+    main()

@@ -176,9 +176,12 @@ __device__ __forceinline__ float group_sum(float v)
 
 // 16-byte streaming load of read-once data (weights, KV): non-temporal so it does not displace
 // the activations in L2 (MI355X guide, row nt-weights).
+// The pointer is cast to the GLOBAL address space explicitly: through struct-carried pointers and
+// selects hipcc otherwise emits flat_load, which counts on vmcnt AND lgkmcnt, completes out of order
+// and forces s_waitcnt vmcnt(0) — i.e. no load pipelining at all.
 __device__ __forceinline__ u32x4 load_nt16(const void *p)
 {
-    return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return __builtin_nontemporal_load((const __attribute__((address_space(1))) u32x4 *)p);
 }
 
 __device__ __forceinline__ float h2f_lo(uint32_t w) { return (float)__builtin_bit_cast(f16x2, w)[0]; }

@@ -1,38 +1,43 @@
 // kernels_attn.hip — single-token attention over the KV cache: the reference's three dispatches
 // AttentionScoreCalculationShader (…ScoreCalculationShader.cs:164-206), AttentionSoftmaxShader
 // (AttentionSoftmaxShader.cs:139-178) and AttentionWeightedValueSumShader
-// (…ValueSumShader.cs:175-216) as ONE pass over K and V.
+// (…ValueSumShader.cs:175-216) as ONE launch and one pass over K and V.
 //
 // Bound: HBM (each cached K/V element is read once per token; 2 flop per element per query head).
-//  - grid = (kv head, KV split): the G = H/Hkv query heads of a kv head share every K/V load (GQA);
-//    the cache positions are cut into up to ATTN_NSPLIT_MAX slices so that a long context fills the
-//    chip; each block writes (max, sum, unnormalised output) for its slice and a second tiny launch
-//    merges the slices (log-sum-exp merge == the reference softmax up to rounding; its
-//    clamp(s - max, -80, 80) only changes terms below e^-80).
-//  - K/V rows go HBM -> VGPR with 16-byte non-temporal loads: D/4 lanes cover one position, so a
-//    wave covers 64/(D/4) positions per load instruction; several positions are in flight per lane.
-//  - scores of the block's slice live in LDS between the two phases; nothing is written to HBM
-//    except the G*(D+2) floats per slice.
-// The number of ACTIVE slices depends on the current sequence length, which is read from device
-// memory (so a captured hipGraph can be replayed for every position); inactive blocks exit.
+//  - grid = (kv head, KV slice): the G = H/Hkv query heads of a kv head share every K/V load (GQA);
+//    the cached positions are cut into up to ATTN_NSPLIT_MAX slices so that a few hundred positions
+//    already fill the chip.  A block computes (max, sum of exp, unnormalised output) of its slice.
+//  - K/V rows go HBM -> VGPR with 16-byte non-temporal loads: D/4 lanes cover one position, a wave
+//    covers 64/(D/4) positions per load instruction; the first four K rows AND the first four V rows
+//    of every lane group are requested before any arithmetic (V does not depend on the scores).
+//  - the scores of the slice stay in LDS between the phases.
+//  - the slices are merged in the SAME launch by the last block of each kv head to finish
+//    (log-sum-exp merge == the reference softmax up to rounding; its clamp(s - max, -80, 80) only
+//    alters terms below e^-80).  Hand-off: every partial word is stored write-through at agent
+//    scope, each storing wave drains its stores, the block's barrier, ONE lane takes a ticket with an
+//    agent-scope atomic; the block whose ticket is last reads the partials with agent-scope loads
+//    after its own barrier (MI355X guide, visibility table row 1).  No result depends on which block
+//    is last: the merge order over slices is fixed (0..nsplit-1), so runs are bit-reproducible.
+// The number of ACTIVE slices depends on the sequence length, which is read from device memory so
+// a captured hipGraph can be replayed for every position; inactive blocks exit at once.
 #include "common.h"
 
 namespace nfai {
 
 constexpr int ATTN_BLOCK = 256;
-constexpr int ATTN_MIN_CHUNK = 16;   // positions per slice before another slice is opened
-constexpr int ATTN_MAX_CHUNK = 1024; // LDS score capacity per query head (positions)
-constexpr int ATTN_GMAX = 8;         // max query heads per kv head
+constexpr int ATTN_MIN_CHUNK = 16;    // positions per slice before another slice is opened
+constexpr int ATTN_MAX_CHUNK = 1024;  // LDS score capacity per query head (positions)
+constexpr int ATTN_GMAX = 8;          // max query heads per kv head
 
 struct AttnParams {
     const float *q;
     const void *kc, *vc;
     uint64_t pos_stride, head_stride;
     float *o;
-    float *partials;  // [Hkv][NSPLIT_MAX][G][D + 2]
+    float *partials;     // [Hkv][NSPLIT_MAX][G][D + 2]
+    uint32_t *tickets;   // [Hkv], zero between launches
     uint32_t H, Hkv, D;
     const uint32_t *pos;
-    int kv_f16;
 };
 
 __device__ __forceinline__ void attn_split(uint32_t S, uint32_t &nsplit, uint32_t &chunk)
@@ -48,22 +53,42 @@ template <bool F16>
 __device__ __forceinline__ f32x4 kv_load4(const void *base, uint64_t idx)
 {
     if constexpr (F16) {
-        const u32x2 w = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(reinterpret_cast<const _Float16 *>(base) + idx));
+        const u32x2 w = __builtin_nontemporal_load(
+            (const __attribute__((address_space(1))) u32x2 *)(reinterpret_cast<const _Float16 *>(base) + idx));
         return f32x4{h2f_lo(w[0]), h2f_hi(w[0]), h2f_lo(w[1]), h2f_hi(w[1])};
     } else {
         const u32x4 w = load_nt16(reinterpret_cast<const float *>(base) + idx);
-        return f32x4{__builtin_bit_cast(float, w[0]), __builtin_bit_cast(float, w[1]), __builtin_bit_cast(float, w[2]),
-                     __builtin_bit_cast(float, w[3])};
+        return __builtin_bit_cast(f32x4, w);  // whole-vector cast (element-wise bit_cast on w[i] reads w[0], hipcc 7.2)
     }
 }
+
+// sum over aligned groups of 16 lanes with DPP (no LDS crossbar); every lane gets its group's sum
+__device__ __forceinline__ float row16_sum(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+template <int LPP> __device__ __forceinline__ float pos_sum(float v)
+{
+    v = row16_sum(v);
+    if constexpr (LPP == 32) v += __shfl_xor(v, 16);
+    return v;
+}
+
+__device__ __forceinline__ void st_agent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // LPP = lanes per position = D/4 (16 for D=64, 32 for D=128); G = query heads per kv head.
 template <int LPP, int G, bool F16>
 __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
 {
     constexpr int D = LPP * 4;
-    constexpr int PPW = 64 / LPP;                 // positions per wave-instruction
-    constexpr int NGRP = ATTN_BLOCK / LPP;        // position groups per block
+    constexpr int NGRP = ATTN_BLOCK / LPP;  // position groups per block
+    constexpr int PF = 4;                   // positions per group per iteration
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const uint32_t S = p.pos[0] + 1;
     uint32_t nsplit, chunk;
@@ -72,30 +97,31 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
     if (split >= nsplit) return;
     const uint32_t t0 = split * chunk, t1 = min(t0 + chunk, S), n = t1 - t0;
 
-    float *stat = smem;                     // [G][2] = (slice max, slice sum of exp)
-    float *sc = smem + 16;                  // [G][chunk_pad]
+    float *stat = smem;               // [G][2] = (slice max, slice sum of exp); [32] = last-block flag
+    float *sc = smem + 64;            // [G][chunk_pad]
     const uint32_t chunk_pad = (chunk + 3) & ~3u;
-    float *red = sc + G * chunk_pad;        // [G][NGRP][D] reduction of the V phase
+    float *red = sc + G * chunk_pad;  // [G][NGRP][D] reduction of the V phase
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t grp = tid / LPP, li = tid % LPP;   // position group, lane within the position
+    const uint32_t grp = tid / LPP, li = tid % LPP;  // position group, lane within the position
 
-    // this lane's 4 elements of each of the G query vectors
+    // ---- requests first: this group's first PF K rows and first PF V rows, then q --------------
+    const uint64_t hbase = (uint64_t)kvh * p.head_stride + li * 4;
+    f32x4 kx[PF], vx[PF];
+#pragma unroll
+    for (int u = 0; u < PF; u++) kx[u] = kv_load4<F16>(p.kc, (uint64_t)(t0 + min(grp + u * NGRP, n - 1)) * p.pos_stride + hbase);
+#pragma unroll
+    for (int u = 0; u < PF; u++) vx[u] = kv_load4<F16>(p.vc, (uint64_t)(t0 + min(grp + u * NGRP, n - 1)) * p.pos_stride + hbase);
     f32x4 qv[G];
 #pragma unroll
-    for (int g = 0; g < G; g++) qv[g] = *reinterpret_cast<const f32x4 *>(p.q + (uint64_t)(kvh * G + g) * D + li * 4);
+    for (int g = 0; g < G; g++)
+        qv[g] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(
+            (const __attribute__((address_space(1))) float *)p.q + (uint64_t)(kvh * G + g) * D + li * 4);
     const float scale = 1.0f / sqrtf((float)D);  // …ScoreCalculationShader.cs:93
 
-    // ---- phase 1: scores of the slice ------------------------------------------------------
-    const uint64_t hbase = (uint64_t)kvh * p.head_stride + li * 4;
-    for (uint32_t i = grp; i < n; i += NGRP * 4) {
-        f32x4 kx[4];
+    // ---- phase 1: scores of the slice -> LDS ------------------------------------------------
+    for (uint32_t i = grp;; i += NGRP * PF) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t ii = i + u * NGRP;
-            kx[u] = kv_load4<F16>(p.kc, (uint64_t)(t0 + min(ii, n - 1)) * p.pos_stride + hbase);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < PF; u++) {
             const uint32_t ii = i + u * NGRP;
 #pragma unroll
             for (int g = 0; g < G; g++) {
@@ -103,16 +129,19 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
                 d = fmaf(qv[g][1], kx[u][1], d);
                 d = fmaf(qv[g][2], kx[u][2], d);
                 d = fmaf(qv[g][3], kx[u][3], d);
-                d = group_sum<LPP>(d);
+                d = pos_sum<LPP>(d);
                 if (li == 0 && ii < n) sc[g * chunk_pad + ii] = d * scale;
             }
         }
+        if (i + NGRP * PF >= n) break;  // uniform per lane group; the sums above stay inside a group
+#pragma unroll
+        for (int u = 0; u < PF; u++)
+            kx[u] = kv_load4<F16>(p.kc, (uint64_t)(t0 + min(i + NGRP * PF + u * NGRP, n - 1)) * p.pos_stride + hbase);
     }
     __syncthreads();
 
-    // ---- phase 2: slice max and exp (AttentionSoftmaxShader.cs:148-169 restricted to the slice) --
-    // wave w handles query heads w, w+4, ...
-    for (uint32_t g = tid >> 6; g < G; g += ATTN_BLOCK / 64) {
+    // ---- phase 2: slice max, exp, sum (AttentionSoftmaxShader.cs:148-169 on the slice) -----------
+    for (uint32_t g = tid >> 6; g < (uint32_t)G; g += ATTN_BLOCK / 64) {  // wave per query head
         float m = -1.0e38f;
         for (uint32_t t = lane; t < n; t += 64) m = fmaxf(m, sc[g * chunk_pad + t]);
         m = wave_max(m);
@@ -131,15 +160,9 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
     f32x4 acc[G];
 #pragma unroll
     for (int g = 0; g < G; g++) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (uint32_t i = grp; i < n; i += NGRP * 4) {
-        f32x4 vx[4];
+    for (uint32_t i = grp;; i += NGRP * PF) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t ii = i + u * NGRP;
-            vx[u] = kv_load4<F16>(p.vc, (uint64_t)(t0 + min(ii, n - 1)) * p.pos_stride + hbase);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < PF; u++) {
             const uint32_t ii = i + u * NGRP;
             if (ii < n) {
 #pragma unroll
@@ -152,11 +175,16 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
                 }
             }
         }
+        if (i + NGRP * PF >= n) break;
+#pragma unroll
+        for (int u = 0; u < PF; u++)
+            vx[u] = kv_load4<F16>(p.vc, (uint64_t)(t0 + min(i + NGRP * PF + u * NGRP, n - 1)) * p.pos_stride + hbase);
     }
     // reduce over position groups through LDS: red[g][grp][D]
 #pragma unroll
     for (int g = 0; g < G; g++) *reinterpret_cast<f32x4 *>(red + ((uint32_t)g * NGRP + grp) * D + li * 4) = acc[g];
     __syncthreads();
+    float *my_part = p.partials + ((uint64_t)kvh * ATTN_NSPLIT_MAX + split) * G * (D + 2);
     for (uint32_t e = tid; e < (uint32_t)G * D; e += ATTN_BLOCK) {
         const uint32_t g = e / D, d = e % D;
         float sum = 0.f;
@@ -166,42 +194,72 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
             // single slice: normalise here (AttentionSoftmaxShader.cs:172-176: e * (1/sum))
             p.o[(uint64_t)(kvh * G + g) * D + d] = sum * (1.0f / stat[g * 2 + 1]);
         } else {
-            p.partials[(((uint64_t)kvh * ATTN_NSPLIT_MAX + split) * G + g) * (D + 2) + d] = sum;
+            st_agent(my_part + g * (D + 2) + d, sum);
         }
     }
-    if (nsplit > 1 && tid < (uint32_t)G) {
-        float *pp = p.partials + (((uint64_t)kvh * ATTN_NSPLIT_MAX + split) * G + tid) * (D + 2) + D;
-        pp[0] = stat[tid * 2];
-        pp[1] = stat[tid * 2 + 1];
+    if (nsplit == 1) return;
+    if (tid < (uint32_t)G) {
+        st_agent(my_part + tid * (D + 2) + D, stat[tid * 2]);
+        st_agent(my_part + tid * (D + 2) + D + 1, stat[tid * 2 + 1]);
     }
-}
+    // ---- hand-off: drain every storing wave, barrier, one ticket per block --------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(&p.tickets[kvh], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stat[32] = (t == nsplit - 1) ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    if (stat[32] == 0.0f) return;
 
-// merge the slices: one block per query head, thread per output element
-template <int DD>
-__global__ __launch_bounds__(DD) void k_attn_merge(const AttnParams p)
-{
-    const uint32_t S = p.pos[0] + 1;
-    uint32_t nsplit, chunk;
-    attn_split(S, nsplit, chunk);
-    if (nsplit == 1) return;  // the decode kernel already wrote the normalised output
-    const uint32_t G = p.H / p.Hkv, h = blockIdx.x, kvh = h / G, g = h % G, d = threadIdx.x;
-    const float *base = p.partials + (((uint64_t)kvh * ATTN_NSPLIT_MAX) * G + g) * (DD + 2);
-    const uint64_t sstride = (uint64_t)G * (DD + 2);
-    float m = -1.0e38f;
-    for (uint32_t s = 0; s < nsplit; s++) m = fmaxf(m, base[s * sstride + DD]);
-    float l = 0.f, o = 0.f;
-    for (uint32_t s = 0; s < nsplit; s++) {
-        const float f = expf(base[s * sstride + DD] - m);
-        l = fmaf(base[s * sstride + DD + 1], f, l);
-        o = fmaf(base[s * sstride + d], f, o);
+    // ---- merge by the last block of this kv head: slices in fixed order 0..nsplit-1 --------------
+    const float *base = p.partials + (uint64_t)kvh * ATTN_NSPLIT_MAX * G * (D + 2);
+    float *mw = sc;  // [G][NSPLIT_MAX][2] = (exp(m_s - M), l_s) — sc is free now
+    for (uint32_t e = tid; e < (uint32_t)G * nsplit; e += ATTN_BLOCK) {
+        const uint32_t g = e / nsplit, s = e % nsplit;
+        const float *pp = base + ((uint64_t)s * G + g) * (D + 2) + D;
+        mw[(g * ATTN_NSPLIT_MAX + s) * 2] = ld_agent(pp);
+        mw[(g * ATTN_NSPLIT_MAX + s) * 2 + 1] = ld_agent(pp + 1);
     }
-    p.o[(uint64_t)h * DD + d] = o * (1.0f / l);
+    __syncthreads();
+    if (tid < (uint32_t)G) {  // per head: global max, merge weights, normaliser (serial over <= 32 slices)
+        float M = -1.0e38f;
+        for (uint32_t s = 0; s < nsplit; s++) M = fmaxf(M, mw[(tid * ATTN_NSPLIT_MAX + s) * 2]);
+        float L = 0.f;
+        for (uint32_t s = 0; s < nsplit; s++) {
+            const float f = expf(mw[(tid * ATTN_NSPLIT_MAX + s) * 2] - M);
+            L = fmaf(mw[(tid * ATTN_NSPLIT_MAX + s) * 2 + 1], f, L);
+            mw[(tid * ATTN_NSPLIT_MAX + s) * 2] = f;
+        }
+        stat[tid * 2] = 1.0f / L;
+    }
+    __syncthreads();
+    for (uint32_t e = tid; e < (uint32_t)G * D; e += ATTN_BLOCK) {
+        const uint32_t g = e / D, d = e % D;
+        const float *pp = base + (uint64_t)g * (D + 2) + d;
+        float o = 0.f;
+        uint32_t s = 0;
+        for (; s + 4 <= nsplit; s += 4) {  // four independent loads in flight
+            const float a0 = ld_agent(pp + (uint64_t)(s + 0) * G * (D + 2));
+            const float a1 = ld_agent(pp + (uint64_t)(s + 1) * G * (D + 2));
+            const float a2 = ld_agent(pp + (uint64_t)(s + 2) * G * (D + 2));
+            const float a3 = ld_agent(pp + (uint64_t)(s + 3) * G * (D + 2));
+            o = fmaf(a0, mw[(g * ATTN_NSPLIT_MAX + s + 0) * 2], o);
+            o = fmaf(a1, mw[(g * ATTN_NSPLIT_MAX + s + 1) * 2], o);
+            o = fmaf(a2, mw[(g * ATTN_NSPLIT_MAX + s + 2) * 2], o);
+            o = fmaf(a3, mw[(g * ATTN_NSPLIT_MAX + s + 3) * 2], o);
+        }
+        for (; s < nsplit; s++) o = fmaf(ld_agent(pp + (uint64_t)s * G * (D + 2)), mw[(g * ATTN_NSPLIT_MAX + s) * 2], o);
+        p.o[(uint64_t)(kvh * G + g) * D + d] = o * stat[g * 2];
+    }
+    if (tid == 0) __hip_atomic_store(&p.tickets[kvh], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
 }
 
 size_t attn_partials_bytes(uint32_t H, uint32_t Hkv, uint32_t D)
 {
+    // one ticket word per kv head (256 B reserved), then partial outputs + (max, sum) per (head, slice)
     (void)Hkv;
-    return (size_t)H * ATTN_NSPLIT_MAX * (D + 2) * sizeof(float);
+    return (size_t)H * ATTN_NSPLIT_MAX * (D + 2) * sizeof(float) + 256;
 }
 
 template <int LPP, bool F16>
@@ -220,33 +278,33 @@ static hipError_t launch_g(const AttnParams &p, uint32_t G, dim3 grid, size_t ld
 
 hipError_t launch_attn_decode(const AttnArgs &a, hipStream_t s)
 {
-    if (a.Hkv == 0 || a.H % a.Hkv != 0) return hipErrorInvalidValue;
+    if (a.Hkv == 0 || a.H % a.Hkv != 0 || a.Hkv > 64) return hipErrorInvalidValue;
     const uint32_t G = a.H / a.Hkv;
     if (G > ATTN_GMAX) return hipErrorInvalidValue;
     if (a.D != 64 && a.D != 128) return hipErrorInvalidValue;
     AttnParams p{};
     p.q = a.q; p.kc = a.kcache; p.vc = a.vcache;
     p.pos_stride = a.kv_pos_stride; p.head_stride = a.kv_head_stride;
-    p.o = a.o; p.partials = a.partials;
+    // workspace layout: [64 ticket words (zero between launches)] [partials]; the tickets sit at a
+    // FIXED offset so that a workspace shared by calls of different shapes never aliases them
+    p.o = a.o;
+    p.tickets = reinterpret_cast<uint32_t *>(a.partials);
+    p.partials = a.partials + 64;
     p.H = a.H; p.Hkv = a.Hkv; p.D = a.D; p.pos = a.pos_dev;
-    p.kv_f16 = a.kv_type == NFAI_F16;
-    // LDS: scores for the largest slice the capacity C can produce + the V-phase reduction
+    // LDS: scalars + scores of the largest slice the capacity C can produce (also holds the merge
+    // weights: G*NSPLIT_MAX*2 floats) + the V-phase reduction
     uint32_t max_chunk = (a.C + ATTN_NSPLIT_MAX - 1) / ATTN_NSPLIT_MAX;
     if (max_chunk < ATTN_MIN_CHUNK) max_chunk = ATTN_MIN_CHUNK;
     if (max_chunk > ATTN_MAX_CHUNK) return hipErrorInvalidValue;  // C <= 32768 positions
     max_chunk = (max_chunk + 3) & ~3u;
+    if (max_chunk < 2 * ATTN_NSPLIT_MAX) max_chunk = 2 * ATTN_NSPLIT_MAX;
     const uint32_t lpp = a.D / 4, ngrp = ATTN_BLOCK / lpp;
-    const size_t lds = ((size_t)G * max_chunk + (size_t)G * ngrp * a.D + 64) * sizeof(float);
+    const size_t lds = (64 + (size_t)G * max_chunk + (size_t)G * ngrp * a.D + 64) * sizeof(float);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     const dim3 grid(a.Hkv, ATTN_NSPLIT_MAX);
-    hipError_t e;
-    const bool f16 = p.kv_f16;
-    if (a.D == 64) e = f16 ? launch_g<16, true>(p, G, grid, lds, s) : launch_g<16, false>(p, G, grid, lds, s);
-    else e = f16 ? launch_g<32, true>(p, G, grid, lds, s) : launch_g<32, false>(p, G, grid, lds, s);
-    if (e != hipSuccess) return e;
-    if (a.D == 64) hipLaunchKernelGGL((k_attn_merge<64>), dim3(a.H), dim3(64), 0, s, p);
-    else hipLaunchKernelGGL((k_attn_merge<128>), dim3(a.H), dim3(128), 0, s, p);
-    return hipGetLastError();
+    const bool f16 = a.kv_type == NFAI_F16;
+    if (a.D == 64) return f16 ? launch_g<16, true>(p, G, grid, lds, s) : launch_g<16, false>(p, G, grid, lds, s);
+    return f16 ? launch_g<32, true>(p, G, grid, lds, s) : launch_g<32, false>(p, G, grid, lds, s);
 }
 
 }  // namespace nfai

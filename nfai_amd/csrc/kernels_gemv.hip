@@ -38,6 +38,8 @@ struct GemvParams {
     int kv_f16;
 };
 
+#define GLOBAL_AS __attribute__((address_space(1)))
+
 template <int WT> struct WTraits;
 template <> struct WTraits<NFAI_F16> { static constexpr int EPL = 8; };  // elements per 16-byte lane load
 template <> struct WTraits<NFAI_F32> { static constexpr int EPL = 4; };
@@ -81,10 +83,12 @@ __device__ __forceinline__ float dot_chunk(u32x4 w, const float *xs, uint32_t ch
         return dot8_f16(w, x0, x1, acc);
     } else {
         const f32x4 x0 = *reinterpret_cast<const f32x4 *>(xs + (chunk << 8) + (lane << 2));
-        acc = fmaf(__builtin_bit_cast(float, w[0]), x0[0], acc);
-        acc = fmaf(__builtin_bit_cast(float, w[1]), x0[1], acc);
-        acc = fmaf(__builtin_bit_cast(float, w[2]), x0[2], acc);
-        acc = fmaf(__builtin_bit_cast(float, w[3]), x0[3], acc);
+        // whole-vector bit cast: __builtin_bit_cast on a vector ELEMENT lvalue reads element 0 (hipcc 7.2)
+        const f32x4 wf = __builtin_bit_cast(f32x4, w);
+        acc = fmaf(wf[0], x0[0], acc);
+        acc = fmaf(wf[1], x0[1], acc);
+        acc = fmaf(wf[2], x0[2], acc);
+        acc = fmaf(wf[3], x0[3], acc);
         return acc;
     }
 }
@@ -146,12 +150,25 @@ __device__ __forceinline__ void epilogue(const GemvParams &p, uint32_t unit, flo
     }
 }
 
-template <int WT, int MODE, int UPW, int U, bool GUARD>
+// Walks a wave's steps: (unit group g, K-chunk group cg).  One walker for the loads that are being
+// issued (two steps ahead) and one for the step being consumed.
+struct StepWalk {
+    uint32_t g = 0, cg = 0;
+    __device__ __forceinline__ void next(uint32_t cpg)
+    {
+        if (++cg == cpg) { cg = 0; ++g; }
+    }
+};
+
+template <int WT, int MODE, int UPW, int U, bool GUARD, bool NORM>
 __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
 {
     constexpr int RPU = (MODE == GEMV_QKV_ROPE || MODE == GEMV_GATEUP) ? 2 : 1;
     constexpr int R = UPW * RPU;
     constexpr int EPL = WTraits<WT>::EPL;
+    // x float4s held per thread across the prologue: 4 covers K <= 16*blockDim (every RMSNorm'd
+    // input: K = n_embd), 16 covers K <= 64*blockDim (the FFN down projection, K = ffn length)
+    constexpr int XN = NORM ? 4 : 16;
     extern __shared__ __attribute__((aligned(16))) float xs[];  // KC*64*EPL floats, then 16 for reductions
 
     const uint32_t lane = threadIdx.x & 63;
@@ -163,49 +180,74 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
     const uint32_t ngroups = (u_end - u_begin + UPW - 1) / UPW;
     const uint32_t cpg = p.KC / U;  // K-chunk groups per unit group
     const uint32_t nsteps = ngroups * cpg;
+    const uint32_t kpad = p.KC * 64 * EPL;
 
-    u32x4 cur[R][U], nxt[R][U];
-    const uint8_t *rows[R];
-    // ---- first step's weight loads go out before anything else: they do not depend on x ----
-    if (nsteps > 0) {
+    // ---- (1) the activation loads go out FIRST: vmcnt retires in order, so the prologue below can
+    //      wait for x while every weight load issued after it stays in flight --------------------
+    f32x4 xv[XN], gv[NORM ? XN : 1];
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const uint32_t u = min(u_begin + r / RPU, u_end - 1);
-            rows[r] = row_ptr<MODE>(p, u, r % RPU);
-            issue_loads<WT, U, GUARD>(cur[r], rows[r], 0, lane, p.K);
-        }
+    for (int i = 0; i < XN; i++) {
+        // unconditional loads from a clamped address + select: a branch around each load would make
+        // hipcc wait vmcnt(0) per element
+        const uint32_t k = (threadIdx.x + i * blockDim.x) * 4;
+        const uint32_t kk = min(k, p.K - 4);
+        const f32x4 v = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.x + kk);
+        xv[i] = k < p.K ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (NORM) gv[i] = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.gamma + kk);
     }
 
-    // ---- prologue: x (optionally RMSNorm'd: RMSNormShader.cs:136-149) -> LDS -----------------
+    // ---- (2) weight loads of the first TWO steps (they do not depend on x) ----------------------
+    u32x4 bufA[R][U], bufB[R][U];
+    const uint8_t *rows[R];
+    StepWalk iw;  // issue walker
+    auto issue = [&](u32x4 (&buf)[R][U]) {
+        if (iw.cg == 0) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint32_t u = min(min(u_begin + iw.g * UPW + r / RPU, u_end - 1), p.NU - 1);
+                rows[r] = row_ptr<MODE>(p, u, r % RPU);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) issue_loads<WT, U, GUARD>(buf[r], rows[r], iw.cg * U, lane, p.K);
+        iw.next(cpg);
+    };
+    // unconditional (row indices are clamped to valid rows): a branch around the issue would make the
+    // compiler's vmcnt bookkeeping take the worst path and wait for the weights before using x
+    issue(bufA);
+    issue(bufB);
+
+    // ---- (3) prologue: x (optionally RMSNorm'd: RMSNormShader.cs:136-149) -> LDS ---------------
     {
-        const uint32_t kpad = p.KC * 64 * EPL;
         float *red = xs + kpad;
-        float inv_rms = 1.f;
-        if (p.gamma != nullptr) {
+        float rms = 1.f;
+        if constexpr (NORM) {
             float ss = 0.f;
-            for (uint32_t k = threadIdx.x * 4; k < p.K; k += blockDim.x * 4) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(p.x + k);
-                ss = fmaf(v[0], v[0], ss);
-                ss = fmaf(v[1], v[1], ss);
-                ss = fmaf(v[2], v[2], ss);
-                ss = fmaf(v[3], v[3], ss);
+#pragma unroll
+            for (int i = 0; i < XN; i++) {
+                ss = fmaf(xv[i][0], xv[i][0], ss);
+                ss = fmaf(xv[i][1], xv[i][1], ss);
+                ss = fmaf(xv[i][2], xv[i][2], ss);
+                ss = fmaf(xv[i][3], xv[i][3], ss);
             }
             ss = block_sum(ss, red);
-            inv_rms = sqrtf(ss / (float)p.K + p.eps);  // rms itself; applied as a division below
+            rms = sqrtf(ss / (float)p.K + p.eps);
         }
-        for (uint32_t k = threadIdx.x * 4; k < kpad; k += blockDim.x * 4) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k < p.K) {
-                v = *reinterpret_cast<const f32x4 *>(p.x + k);
-                if (p.gamma != nullptr) {
-                    const f32x4 g = *reinterpret_cast<const f32x4 *>(p.gamma + k);
-                    v[0] = (v[0] / inv_rms) * g[0];
-                    v[1] = (v[1] / inv_rms) * g[1];
-                    v[2] = (v[2] / inv_rms) * g[2];
-                    v[3] = (v[3] / inv_rms) * g[3];
+#pragma unroll
+        for (int i = 0; i < XN; i++) {
+            const uint32_t k = (threadIdx.x + i * blockDim.x) * 4;
+            if (k < kpad) {
+                f32x4 v = xv[i];
+                if constexpr (NORM) {
+                    if (k < p.K) {
+                        v[0] = (v[0] / rms) * gv[i][0];
+                        v[1] = (v[1] / rms) * gv[i][1];
+                        v[2] = (v[2] / rms) * gv[i][2];
+                        v[3] = (v[3] / rms) * gv[i][3];
+                    }
                 }
+                *reinterpret_cast<f32x4 *>(xs + xs_index<EPL>(k)) = v;
             }
-            *reinterpret_cast<f32x4 *>(xs + xs_index<EPL>(k)) = v;
         }
         __syncthreads();
     }
@@ -214,57 +256,64 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.f;
 
-    uint32_t g = 0, cg = 0;
-    for (uint32_t st = 0; st < nsteps; st++) {
-        uint32_t ng = g, ncg = cg + 1;
-        if (ncg == cpg) { ncg = 0; ng = g + 1; }
-        if (st + 1 < nsteps) {
-            if (ncg == 0) {
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const uint32_t u = min(u_begin + ng * UPW + r / RPU, u_end - 1);
-                    rows[r] = row_ptr<MODE>(p, u, r % RPU);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < R; r++) issue_loads<WT, U, GUARD>(nxt[r], rows[r], ncg * U, lane, p.K);
-        }
+    StepWalk cw;  // compute walker
+    auto consume = [&](u32x4 (&buf)[R][U]) {
 #pragma unroll
         for (int j = 0; j < U; j++) {
 #pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = dot_chunk<WT>(cur[r][j], xs, cg * U + j, lane, acc[r]);
+            for (int r = 0; r < R; r++) acc[r] = dot_chunk<WT>(buf[r][j], xs, cw.cg * U + j, lane, acc[r]);
         }
-        if (cg == cpg - 1) {
+        if (cw.cg == cpg - 1) {
 #pragma unroll
             for (int r = 0; r < R; r++) acc[r] = wave_sum(acc[r]);
 #pragma unroll
             for (int q = 0; q < UPW; q++) {
-                const uint32_t u = u_begin + g * UPW + q;
+                const uint32_t u = u_begin + cw.g * UPW + q;
                 // lane q finishes unit q (uniform values; spreads the stores over lanes)
                 if (lane == (uint32_t)q && u < u_end) epilogue<MODE>(p, u, acc[q * RPU], RPU == 2 ? acc[q * RPU + RPU - 1] : 0.f);
             }
 #pragma unroll
             for (int r = 0; r < R; r++) acc[r] = 0.f;
         }
-#pragma unroll
-        for (int r = 0; r < R; r++)
-#pragma unroll
-            for (int j = 0; j < U; j++) cur[r][j] = nxt[r][j];
-        g = ng;
-        cg = ncg;
+        cw.next(cpg);
+    };
+
+    // ---- (4) ping-pong: consume A, refill A with step+2, consume B, refill B with step+3.  No
+    //      register copies (a copy of an in-flight load's destination would wait for it) ----------
+    //      Refills inside the loop are unconditional so every wait is an exact count; the last
+    //      one to three steps are peeled.
+    uint32_t st = 0;
+    for (; st + 3 < nsteps; st += 2) {
+        consume(bufA);
+        issue(bufA);
+        consume(bufB);
+        issue(bufB);
+    }
+    const uint32_t rem = nsteps - st;  // 0 (no work) .. 3
+    if (rem == 3) {
+        consume(bufA);
+        issue(bufA);
+        consume(bufB);
+        consume(bufA);
+    } else if (rem == 2) {
+        consume(bufA);
+        consume(bufB);
+    } else if (rem == 1) {
+        consume(bufA);
     }
 }
 
 // ---- host side: shape checks and the (waves per block, units per wave step, K unroll) choice ----
 struct GemvPlan {
     int upw, u;
-    bool guard;
+    bool guard, ok;
     uint32_t grid, block, lds_bytes;
 };
 
-static GemvPlan plan_gemv(uint32_t NU, uint32_t K, int epl, int rpu, uint32_t n_cu)
+static GemvPlan plan_gemv(uint32_t NU, uint32_t K, int epl, int rpu, uint32_t n_cu, bool norm)
 {
     GemvPlan pl{};
+    pl.ok = true;
     const uint32_t ce = 64u * epl;
     pl.guard = (K % ce) != 0;
     const uint32_t kc = (K + ce - 1) / ce;
@@ -287,6 +336,10 @@ static GemvPlan plan_gemv(uint32_t NU, uint32_t K, int epl, int rpu, uint32_t n_
     for (int c = 4; c >= 1; c--) {
         if (c * rpu * pl.u <= 16 && upw_total % c == 0) { upw = c; break; }
     }
+    // the block must hold x in XN float4 per thread (XN = 4 with RMSNorm, 16 without)
+    const uint32_t xn = norm ? 4 : 16;
+    while (wpb < 8 && (uint64_t)xn * wpb * 64 * 4 < (uint64_t)kc * ce) wpb++;
+    if ((uint64_t)xn * wpb * 64 * 4 < (uint64_t)kc * ce) pl.ok = false;
     pl.upw = upw;
     pl.grid = grid;
     pl.block = wpb * 64;
@@ -297,7 +350,10 @@ static GemvPlan plan_gemv(uint32_t NU, uint32_t K, int epl, int rpu, uint32_t n_
 template <int WT, int MODE, int UPW, int U, bool GUARD>
 static hipError_t launch_one(const GemvParams &p, const GemvPlan &pl, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_gemv<WT, MODE, UPW, U, GUARD>), dim3(pl.grid), dim3(pl.block), pl.lds_bytes, s, p);
+    if (p.gamma != nullptr)
+        hipLaunchKernelGGL((k_gemv<WT, MODE, UPW, U, GUARD, true>), dim3(pl.grid), dim3(pl.block), pl.lds_bytes, s, p);
+    else
+        hipLaunchKernelGGL((k_gemv<WT, MODE, UPW, U, GUARD, false>), dim3(pl.grid), dim3(pl.block), pl.lds_bytes, s, p);
     return hipGetLastError();
 }
 
@@ -376,7 +432,8 @@ hipError_t launch_gemv(const GemvArgs &a, hipStream_t s)
     p.D = a.D;
     p.pos = a.pos_dev;
     p.kv_f16 = a.kv_type == NFAI_F16;
-    const GemvPlan pl = plan_gemv(p.NU, a.K, epl, rpu, a.n_cu);
+    const GemvPlan pl = plan_gemv(p.NU, a.K, epl, rpu, a.n_cu, a.gamma != nullptr);
+    if (!pl.ok) return hipErrorInvalidValue;
     p.KC = (a.K + 64 * epl - 1) / (64 * epl);
     if (pl.lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     if (a.w_type == NFAI_F16) return dispatch_mode<NFAI_F16>(p, pl, a.mode, s);

@@ -34,10 +34,32 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def effective_cpus() -> int:
+    """CPUs this process may really use: min(affinity mask, cgroup quota).  On a shared GPU host
+    os.cpu_count() is the whole machine while the container gets a slice; an OpenMP team sized to
+    the machine spins on a few cores and makes every parallel region milliseconds long."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, 64))
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         build()
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+        os.environ.setdefault("OMP_NUM_THREADS", str(effective_cpus()))
         L = C.CDLL(_SO)
         f32p, u16p, u8p, u32, f32 = (C.POINTER(C.c_float), C.POINTER(C.c_uint16),
                                       C.POINTER(C.c_uint8), C.c_uint32, C.c_float)
@@ -85,6 +107,7 @@ def lib() -> C.CDLL:
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        L.orc_set_num_threads(min(effective_cpus(), max(1, L.orc_num_threads())))
         _lib = L
     return _lib
 

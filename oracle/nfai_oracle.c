@@ -147,15 +147,28 @@ ORC_API void orc_gemv(const float *W, const float *x, float *y, uint32_t N, uint
 /* Same GEMV on fp16 storage: operand values are identical to the widened fp32 copy the
  * reference uploads (AbstractComputeCollection.cs:62-77), so results are bit-identical to
  * orc_gemv on the widened matrix.  Used so big-model baselines need 2 B/weight of host RAM. */
+static float *g_h2f_table; /* 65536 exact widenings; built once (idempotent, so a race only repeats work) */
+
+static const float *h2f_table(void)
+{
+    if (!g_h2f_table) {
+        float *t = (float *)malloc(65536 * sizeof(float));
+        for (uint32_t i = 0; i < 65536; i++) t[i] = orc_half_to_float((uint16_t)i);
+        g_h2f_table = t;
+    }
+    return g_h2f_table;
+}
+
 ORC_API void orc_gemv_f16w(const uint16_t *W, const float *x, float *y, uint32_t N, uint32_t K)
 {
+    const float *tab = h2f_table();
 #pragma omp parallel for schedule(static)
     for (uint32_t j = 0; j < N; j++) {
         const uint16_t *w = W + (size_t)j * K;
         float sum = 0.0f;
         for (uint32_t k = 0; k < K; k++) {
             float a = x[k];
-            float b = orc_half_to_float(w[k]);
+            float b = tab[w[k]];
             sum += a * b;
         }
         y[j] = sum;
