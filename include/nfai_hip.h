@@ -208,8 +208,14 @@ int32_t nfai_hip_llama_prefill(nfai_model_t model, const uint32_t *tokens, uint3
 /* Pipeline stage: run this stage's blocks on a hidden state resident in device memory.
  * First stage: hidden_in == NULL and `token` is embedded.  Last stage: lm_head + argmax run and
  * `logits_host`/`argmax` are filled (blocking) when non-NULL.  Otherwise enqueue only. */
+#define NFAI_TOKEN_ON_DEVICE 0xFFFFFFFFu /* stage_step: use the token word already in device memory */
 int32_t nfai_hip_llama_stage_step(nfai_model_t model, uint32_t token, const void *hidden_in_dev,
                                   void *hidden_out_dev, float *logits_host, uint32_t *argmax);
+/* 4-byte device-to-device copies of the model's token word (the last stage's argmax / the first
+ * stage's next input), stream-ordered: lets RCCL carry the token between pipeline ends with no
+ * host round trip (the reference reads V logits back and samples on the host, LlamaModel.cs:128-130). */
+int32_t nfai_hip_llama_token_to_device(nfai_model_t model, void *dst_dev);
+int32_t nfai_hip_llama_token_from_device(nfai_model_t model, const void *src_dev);
 int32_t nfai_hip_llama_reset(nfai_model_t model);   /* ≙ MatrixMultiplyShader.ResetCache (:153-159) + currentToken = 0 */
 int32_t nfai_hip_llama_set_pos(nfai_model_t model, uint32_t pos);
 int32_t nfai_hip_llama_pos(nfai_model_t model, uint32_t *pos);

@@ -10,6 +10,7 @@ SO_PATH = os.path.join(_HERE, "csrc", "libnfai_hip.so")
 OK, ERR_INVALID, ERR_HIP, ERR_OOM, ERR_KV_FULL, ERR_UNSUPPORTED, ERR_STATE = range(7)
 F32, F16, Q4_K, Q6_K = 0, 1, 12, 14
 LLAMA_UNFUSED, LLAMA_NO_GRAPH, LLAMA_KV_F16 = 1, 2, 4
+TOKEN_ON_DEVICE = 0xFFFFFFFF
 
 
 class NfaiHipError(RuntimeError):
@@ -87,6 +88,8 @@ SIGNATURES = {
     "nfai_hip_llama_fetch_tokens": [H, u32, C.POINTER(u32)],
     "nfai_hip_llama_prefill": [H, C.POINTER(u32), u32, C.POINTER(f32)],
     "nfai_hip_llama_stage_step": [H, u32, vp, vp, C.POINTER(f32), C.POINTER(u32)],
+    "nfai_hip_llama_token_to_device": [H, vp],
+    "nfai_hip_llama_token_from_device": [H, vp],
     "nfai_hip_llama_reset": [H],
     "nfai_hip_llama_set_pos": [H, u32],
     "nfai_hip_llama_pos": [H, C.POINTER(u32)],

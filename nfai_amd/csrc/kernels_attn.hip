@@ -214,42 +214,29 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
 
     // ---- merge by the last block of this kv head: slices in fixed order 0..nsplit-1 --------------
     const float *base = p.partials + (uint64_t)kvh * ATTN_NSPLIT_MAX * G * (D + 2);
-    float *mw = sc;  // [G][NSPLIT_MAX][2] = (exp(m_s - M), l_s) — sc is free now
-    for (uint32_t e = tid; e < (uint32_t)G * nsplit; e += ATTN_BLOCK) {
-        const uint32_t g = e / nsplit, s = e % nsplit;
-        const float *pp = base + ((uint64_t)s * G + g) * (D + 2) + D;
-        mw[(g * ATTN_NSPLIT_MAX + s) * 2] = ld_agent(pp);
-        mw[(g * ATTN_NSPLIT_MAX + s) * 2 + 1] = ld_agent(pp + 1);
-    }
-    __syncthreads();
-    if (tid < (uint32_t)G) {  // per head: global max, merge weights, normaliser (serial over <= 32 slices)
-        float M = -1.0e38f;
-        for (uint32_t s = 0; s < nsplit; s++) M = fmaxf(M, mw[(tid * ATTN_NSPLIT_MAX + s) * 2]);
-        float L = 0.f;
-        for (uint32_t s = 0; s < nsplit; s++) {
-            const float f = expf(mw[(tid * ATTN_NSPLIT_MAX + s) * 2] - M);
-            L = fmaf(mw[(tid * ATTN_NSPLIT_MAX + s) * 2 + 1], f, L);
-            mw[(tid * ATTN_NSPLIT_MAX + s) * 2] = f;
-        }
-        stat[tid * 2] = 1.0f / L;
+    float *mw = sc;  // [G][NSPLIT_MAX] merge weights exp(m_s - M), zero for inactive slices — sc is free now
+    // merge weights: one wave per query head, lane = slice (no serial loop over slices)
+    for (uint32_t g = tid >> 6; g < (uint32_t)G; g += ATTN_BLOCK / 64) {
+        const uint32_t sl = min(lane, nsplit - 1);
+        const float *pp = base + ((uint64_t)sl * G + g) * (D + 2) + D;
+        const float m_s = ld_agent(pp), l_s = ld_agent(pp + 1);
+        const float M = wave_max(lane < nsplit ? m_s : -1.0e38f);
+        const float f = lane < nsplit ? expf(m_s - M) : 0.0f;
+        const float L = wave_sum(l_s * f);
+        if (lane < ATTN_NSPLIT_MAX) mw[g * ATTN_NSPLIT_MAX + lane] = f;
+        if (lane == 0) stat[g * 2] = 1.0f / L;
     }
     __syncthreads();
     for (uint32_t e = tid; e < (uint32_t)G * D; e += ATTN_BLOCK) {
         const uint32_t g = e / D, d = e % D;
         const float *pp = base + (uint64_t)g * (D + 2) + d;
+        // every slice's partial is requested before the first is used (clamped address, zero weight)
+        float a[ATTN_NSPLIT_MAX];
+#pragma unroll
+        for (int s2 = 0; s2 < (int)ATTN_NSPLIT_MAX; s2++) a[s2] = ld_agent(pp + (uint64_t)min((uint32_t)s2, nsplit - 1) * G * (D + 2));
         float o = 0.f;
-        uint32_t s = 0;
-        for (; s + 4 <= nsplit; s += 4) {  // four independent loads in flight
-            const float a0 = ld_agent(pp + (uint64_t)(s + 0) * G * (D + 2));
-            const float a1 = ld_agent(pp + (uint64_t)(s + 1) * G * (D + 2));
-            const float a2 = ld_agent(pp + (uint64_t)(s + 2) * G * (D + 2));
-            const float a3 = ld_agent(pp + (uint64_t)(s + 3) * G * (D + 2));
-            o = fmaf(a0, mw[(g * ATTN_NSPLIT_MAX + s + 0) * 2], o);
-            o = fmaf(a1, mw[(g * ATTN_NSPLIT_MAX + s + 1) * 2], o);
-            o = fmaf(a2, mw[(g * ATTN_NSPLIT_MAX + s + 2) * 2], o);
-            o = fmaf(a3, mw[(g * ATTN_NSPLIT_MAX + s + 3) * 2], o);
-        }
-        for (; s < nsplit; s++) o = fmaf(ld_agent(pp + (uint64_t)s * G * (D + 2)), mw[(g * ATTN_NSPLIT_MAX + s) * 2], o);
+#pragma unroll
+        for (int s2 = 0; s2 < (int)ATTN_NSPLIT_MAX; s2++) o = fmaf(a[s2], mw[g * ATTN_NSPLIT_MAX + s2], o);
         p.o[(uint64_t)(kvh * G + g) * D + d] = o * stat[g * 2];
     }
     if (tid == 0) __hip_atomic_store(&p.tickets[kvh], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm

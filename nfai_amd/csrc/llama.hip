@@ -62,6 +62,10 @@ struct Model {
     uint32_t pos_host = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t stage_graph = nullptr;      // pipeline-stage graph, captured per (hidden_in, hidden_out)
+    hipGraphExec_t stage_exec = nullptr;
+    const void *stage_in = nullptr;
+    void *stage_out = nullptr;
     // profiling
     std::vector<hipEvent_t> ev;
     std::vector<int> ev_class;
@@ -428,6 +432,8 @@ NFAI_API int32_t nfai_hip_llama_destroy(nfai_model_t h)
     hipStreamSynchronize(m->ctx->stream);
     if (m->graph_exec) hipGraphExecDestroy(m->graph_exec);
     if (m->graph) hipGraphDestroy(m->graph);
+    if (m->stage_exec) hipGraphExecDestroy(m->stage_exec);
+    if (m->stage_graph) hipGraphDestroy(m->stage_graph);
     for (hipEvent_t e : m->ev) hipEventDestroy(e);
     auto free_t = [](Tensor &t) { if (t.owned && t.ptr) hipFree(t.ptr); };
     free_t(m->token_embd); free_t(m->output_norm); free_t(m->output);
@@ -600,6 +606,18 @@ NFAI_API int32_t nfai_hip_llama_prefill(nfai_model_t h, const uint32_t *tokens, 
     return NFAI_OK;
 }
 
+// The stage's work for one token: hidden state in -> this stage's blocks -> hidden state out
+// (or lm_head + argmax on the last stage).  Captured once per (hidden_in, hidden_out) pair.
+static int stage_enqueue(Model *m, const void *hidden_in, void *hidden_out)
+{
+    hipStream_t s = m->ctx->stream;
+    if (!m->first_stage) HIP_TRY(hipMemcpyAsync(m->x, hidden_in, (size_t)m->d.E * 4, hipMemcpyDeviceToDevice, s));
+    int rc = enqueue_token(m, true);
+    if (rc) return rc;
+    if (!m->last_stage) HIP_TRY(hipMemcpyAsync(hidden_out, m->x, (size_t)m->d.E * 4, hipMemcpyDeviceToDevice, s));
+    return NFAI_OK;
+}
+
 NFAI_API int32_t nfai_hip_llama_stage_step(nfai_model_t h, uint32_t token, const void *hidden_in, void *hidden_out,
                                            float *logits_host, uint32_t *argmax)
 {
@@ -608,27 +626,62 @@ NFAI_API int32_t nfai_hip_llama_stage_step(nfai_model_t h, uint32_t token, const
     hipStream_t s = m->ctx->stream;
     if (m->pos_host >= m->d.C) return fail(NFAI_ERR_KV_FULL, "stage_step: KV cache full at position %u", m->pos_host);
     if (m->first_stage) {
-        if (token >= m->d.V) return fail(NFAI_ERR_INVALID, "stage_step: token %u >= vocab %u", token, m->d.V);
-        int rc = set_token_async(m, token);
-        if (rc) return rc;
+        if (token != NFAI_TOKEN_ON_DEVICE) {
+            if (token >= m->d.V) return fail(NFAI_ERR_INVALID, "stage_step: token %u >= vocab %u", token, m->d.V);
+            int rc = set_token_async(m, token);
+            if (rc) return rc;
+        }
+    } else if (!hidden_in) {
+        return fail(NFAI_ERR_INVALID, "stage_step: hidden_in is required on a non-first stage");
+    }
+    if (!m->last_stage && !hidden_out) return fail(NFAI_ERR_INVALID, "stage_step: hidden_out is required on a non-last stage");
+    if (m->use_graph && !m->unfused) {
+        if (!m->stage_exec || m->stage_in != hidden_in || m->stage_out != hidden_out) {
+            if (m->stage_exec) { hipGraphExecDestroy(m->stage_exec); m->stage_exec = nullptr; }
+            if (m->stage_graph) { hipGraphDestroy(m->stage_graph); m->stage_graph = nullptr; }
+            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            int rc = stage_enqueue(m, hidden_in, hidden_out);
+            hipGraph_t g = nullptr;
+            hipError_t e = hipStreamEndCapture(s, &g);
+            if (rc) { if (g) hipGraphDestroy(g); return rc; }
+            if (e != hipSuccess) return fail(NFAI_ERR_HIP, "stage_step: hipStreamEndCapture failed: %s", hipGetErrorString(e));
+            m->stage_graph = g;
+            HIP_TRY(hipGraphInstantiate(&m->stage_exec, g, nullptr, nullptr, 0));
+            m->stage_in = hidden_in;
+            m->stage_out = hidden_out;
+        }
+        HIP_TRY(hipGraphLaunch(m->stage_exec, s));
     } else {
-        if (!hidden_in) return fail(NFAI_ERR_INVALID, "stage_step: hidden_in is required on a non-first stage");
-        HIP_TRY(hipMemcpyAsync(m->x, hidden_in, (size_t)m->d.E * 4, hipMemcpyDeviceToDevice, s));
+        int rc = stage_enqueue(m, hidden_in, hidden_out);
+        if (rc) return rc;
     }
-    int rc = enqueue_token(m, true);
-    if (rc) return rc;
     m->pos_host++;
-    if (!m->last_stage) {
-        if (!hidden_out) return fail(NFAI_ERR_INVALID, "stage_step: hidden_out is required on a non-last stage");
-        HIP_TRY(hipMemcpyAsync(hidden_out, m->x, (size_t)m->d.E * 4, hipMemcpyDeviceToDevice, s));
-        return NFAI_OK;
-    }
-    if (logits_host || argmax) {
+    if (m->last_stage && (logits_host || argmax)) {
         if (logits_host) HIP_TRY(hipMemcpyAsync(logits_host, m->logits, (size_t)m->d.V * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(m->h_pin, m->d_tok, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         if (argmax) *argmax = m->h_pin[0];
     }
+    return NFAI_OK;
+}
+
+// Token hand-over between pipeline ends without a host round trip: 4-byte device-to-device copies
+// on the context stream (the last stage's argmax -> a buffer RCCL sends; the received buffer ->
+// the first stage's token word).
+NFAI_API int32_t nfai_hip_llama_token_to_device(nfai_model_t h, void *dst_dev)
+{
+    MODEL_OR_FAIL(m, h);
+    if (!dst_dev) return fail(NFAI_ERR_INVALID, "token_to_device: null pointer");
+    HIP_TRY(hipMemcpyAsync(dst_dev, m->d_tok, 4, hipMemcpyDeviceToDevice, m->ctx->stream));
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_llama_token_from_device(nfai_model_t h, const void *src_dev)
+{
+    MODEL_OR_FAIL(m, h);
+    if (!src_dev) return fail(NFAI_ERR_INVALID, "token_from_device: null pointer");
+    HIP_TRY(hipMemcpyAsync(m->d_tok, src_dev, 4, hipMemcpyDeviceToDevice, m->ctx->stream));
     return NFAI_OK;
 }
 

