@@ -215,7 +215,18 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
     // ---- merge by the last block of this kv head: slices in fixed order 0..nsplit-1 --------------
     const float *base = p.partials + (uint64_t)kvh * ATTN_NSPLIT_MAX * G * (D + 2);
     float *mw = sc;  // [G][NSPLIT_MAX] merge weights exp(m_s - M), zero for inactive slices — sc is free now
-    // merge weights: one wave per query head, lane = slice (no serial loop over slices)
+    // ONE memory round trip: every thread requests all slices of its output elements (clamped
+    // address, zero weight for inactive slices) and the per-slice (max, sum) pairs before anything
+    // is used; the merge weights are then computed by one wave per query head (lane = slice).
+    constexpr int EIT = (G * D + ATTN_BLOCK - 1) / ATTN_BLOCK;
+    float a[EIT][ATTN_NSPLIT_MAX];
+#pragma unroll
+    for (int it = 0; it < EIT; it++) {
+        const uint32_t e = min(tid + it * ATTN_BLOCK, (uint32_t)G * D - 1);
+        const float *pp = base + (uint64_t)(e / D) * (D + 2) + (e % D);
+#pragma unroll
+        for (int s2 = 0; s2 < (int)ATTN_NSPLIT_MAX; s2++) a[it][s2] = ld_agent(pp + (uint64_t)min((uint32_t)s2, nsplit - 1) * G * (D + 2));
+    }
     for (uint32_t g = tid >> 6; g < (uint32_t)G; g += ATTN_BLOCK / 64) {
         const uint32_t sl = min(lane, nsplit - 1);
         const float *pp = base + ((uint64_t)sl * G + g) * (D + 2) + D;
@@ -227,17 +238,16 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
         if (lane == 0) stat[g * 2] = 1.0f / L;
     }
     __syncthreads();
-    for (uint32_t e = tid; e < (uint32_t)G * D; e += ATTN_BLOCK) {
-        const uint32_t g = e / D, d = e % D;
-        const float *pp = base + (uint64_t)g * (D + 2) + d;
-        // every slice's partial is requested before the first is used (clamped address, zero weight)
-        float a[ATTN_NSPLIT_MAX];
 #pragma unroll
-        for (int s2 = 0; s2 < (int)ATTN_NSPLIT_MAX; s2++) a[s2] = ld_agent(pp + (uint64_t)min((uint32_t)s2, nsplit - 1) * G * (D + 2));
-        float o = 0.f;
+    for (int it = 0; it < EIT; it++) {
+        const uint32_t e = tid + it * ATTN_BLOCK;
+        if (e < (uint32_t)G * D) {
+            const uint32_t g = e / D, d = e % D;
+            float o = 0.f;
 #pragma unroll
-        for (int s2 = 0; s2 < (int)ATTN_NSPLIT_MAX; s2++) o = fmaf(a[s2], mw[g * ATTN_NSPLIT_MAX + s2], o);
-        p.o[(uint64_t)(kvh * G + g) * D + d] = o * stat[g * 2];
+            for (int s2 = 0; s2 < (int)ATTN_NSPLIT_MAX; s2++) o = fmaf(a[it][s2], mw[g * ATTN_NSPLIT_MAX + s2], o);
+            p.o[(uint64_t)(kvh * G + g) * D + d] = o * stat[g * 2];
+        }
     }
     if (tid == 0) __hip_atomic_store(&p.tickets[kvh], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
 }

@@ -114,15 +114,33 @@ __device__ __forceinline__ void kv_store(void *base, int f16, uint64_t idx, floa
     else reinterpret_cast<float *>(base)[idx] = v;
 }
 
+// What the epilogue of `unit` will read from memory, requested when the unit's first K step is
+// consumed so the latency is hidden behind the rest of the row (a load issued in the epilogue
+// itself would add a full memory round trip to every short kernel).  Unconditional, clamped.
+template <int MODE>
+__device__ __forceinline__ void epilogue_prefetch(const GemvParams &p, uint32_t unit, float &e0, float &e1)
+{
+    if constexpr (MODE == GEMV_RESIDUAL) {
+        e0 = ((const GLOBAL_AS float *)p.res)[unit];
+    } else if constexpr (MODE == GEMV_QKV_ROPE) {
+        const uint32_t row = unit * 2;
+        const uint32_t r = row < p.seg_end[0] ? row : (row < p.seg_end[1] ? row - p.seg_end[0] : row - p.seg_end[1]);
+        const uint32_t d = min(r % p.D, max(p.rope_dims, 2u) - 2);
+        const f32x2 cs = *reinterpret_cast<const GLOBAL_AS f32x2 *>((const GLOBAL_AS float *)p.rope_cs + d);  // [pair][2], pair = d/2
+        e0 = cs[0];
+        e1 = cs[1];
+    }
+}
+
 // Epilogue of one unit; called by one lane with the fully reduced sums.
 template <int MODE>
-__device__ __forceinline__ void epilogue(const GemvParams &p, uint32_t unit, float a0, float a1)
+__device__ __forceinline__ void epilogue(const GemvParams &p, uint32_t unit, float a0, float a1, float e0, float e1, uint32_t pos)
 {
     if constexpr (MODE == GEMV_PLAIN) {
         p.y[unit] = a0;
     } else if constexpr (MODE == GEMV_RESIDUAL) {
         // host residual add of TransformerBlock.cs:153-158 / 176-180: input + projection
-        p.y[unit] = p.res[unit] + a0;
+        p.y[unit] = e0 + a0;
     } else if constexpr (MODE == GEMV_GATEUP) {
         // SiLUShader.cs:121-123 on the gate, ElementWiseMultiplicationShader.cs:137 with A = up
         p.y[unit] = a1 * silu_ref(a0);
@@ -134,15 +152,14 @@ __device__ __forceinline__ void epilogue(const GemvParams &p, uint32_t unit, flo
         const uint32_t head = r / p.D, d = r % p.D;
         float o0 = a0, o1 = a1;
         if (seg < 2 && d < p.rope_dims) {
-            const float c = p.rope_cs[d], sn = p.rope_cs[d + 1];  // [pair][2] with pair = d/2
-            o0 = c * a0 - sn * a1;
-            o1 = sn * a0 + c * a1;
+            o0 = e0 * a0 - e1 * a1;
+            o1 = e1 * a0 + e0 * a1;
         }
         if (seg == 0) {
             p.y[row] = o0;
             p.y[row + 1] = o1;
         } else {
-            const uint64_t idx = (uint64_t)p.pos[0] * p.kv_pos_stride + (uint64_t)head * p.kv_head_stride + d;
+            const uint64_t idx = (uint64_t)pos * p.kv_pos_stride + (uint64_t)head * p.kv_head_stride + d;
             void *base = seg == 1 ? p.kc : p.vc;
             kv_store(base, p.kv_f16, idx, o0);
             kv_store(base, p.kv_f16, idx + 1, o1);
@@ -195,6 +212,12 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
         xv[i] = k < p.K ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (NORM) gv[i] = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.gamma + kk);
     }
+
+    // lane q < UPW finishes unit q of each group: what its FIRST epilogue reads (residual element /
+    // cos,sin pair) and the position are requested now, with the activations
+    float e0 = 0.f, e1 = 0.f;
+    epilogue_prefetch<MODE>(p, min(min(u_begin + min(lane, (uint32_t)UPW - 1), u_end - 1), p.NU - 1), e0, e1);
+    const uint32_t pos_v = (MODE == GEMV_QKV_ROPE) ? p.pos[0] : 0u;
 
     // ---- (2) weight loads of the first TWO steps (they do not depend on x) ----------------------
     u32x4 bufA[R][U], bufB[R][U];
@@ -270,10 +293,13 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
             for (int q = 0; q < UPW; q++) {
                 const uint32_t u = u_begin + cw.g * UPW + q;
                 // lane q finishes unit q (uniform values; spreads the stores over lanes)
-                if (lane == (uint32_t)q && u < u_end) epilogue<MODE>(p, u, acc[q * RPU], RPU == 2 ? acc[q * RPU + RPU - 1] : 0.f);
+                if (lane == (uint32_t)q && u < u_end)
+                    epilogue<MODE>(p, u, acc[q * RPU], RPU == 2 ? acc[q * RPU + RPU - 1] : 0.f, e0, e1, pos_v);
             }
 #pragma unroll
             for (int r = 0; r < R; r++) acc[r] = 0.f;
+            // what the NEXT group's epilogue reads, a whole group ahead
+            epilogue_prefetch<MODE>(p, min(min(u_begin + (cw.g + 1) * UPW + min(lane, (uint32_t)UPW - 1), u_end - 1), p.NU - 1), e0, e1);
         }
         cw.next(cpg);
     };
