@@ -42,15 +42,38 @@ def parse():
     ap.add_argument("--context", type=int, default=CONTEXT)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=0, help="tokens of the CPU baseline sample (0 = auto)")
+    ap.add_argument("--quant", default="f16", choices=["f16", "q4_k_m"], help="GGUF file type of the synthetic weights")
     ap.add_argument("--kv-f16", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=6)
     return ap.parse_args()
 
 
-def gen_weights_hbm(torch, dims, layer_range, first, last, seed=1234):
-    """Random-init weights of the architecture, generated on the GPU, fp16 matrices / fp32 gains
-    (same distribution as nfai_amd.synth.make_weights; torch's generator instead of NumPy's)."""
+Q4_K, Q6_K = 12, 14
+
+
+def use_more_bits(i: int, n: int) -> bool:
+    """llama.cpp's Q4_K_M rule for which blocks keep attn_v / ffn_down in Q6_K."""
+    return i < n // 8 or i >= 7 * n // 8 or (i - n // 8) % 3 == 2
+
+
+def tensor_type(name: str, dims, quant: str) -> int:
+    """ggml type of a matrix under the requested file type (norm gains are always F32)."""
+    if quant == "f16":
+        return 1
+    assert quant == "q4_k_m"
+    if name in ("token_embd.weight", "output.weight"):
+        return Q6_K
+    if name.startswith("blk.") and name.endswith(("attn_v.weight", "ffn_down.weight")):
+        return Q6_K if use_more_bits(int(name.split(".")[1]), dims.L) else Q4_K
+    return Q4_K
+
+
+def gen_weights_hbm(torch, dims, layer_range, first, last, seed=1234, quant="f16"):
+    """Random-init weights of the architecture generated directly in HBM: name -> (tensor, ggml_type,
+    rows, cols).  fp16: N(0, 0.02^2) matrices, 1 + N(0, 0.1^2) gains (nfai_amd.synth distribution).
+    q4_k_m: random K-quant super-blocks (random 4/6-bit codes and 6/8-bit sub-scales, fixed small
+    fp16 d / dmin so the dequantised weights are ~0.02 in magnitude) in the Q4_K_M tensor mix."""
     g = torch.Generator(device="cuda")
     g.manual_seed(seed)
     out = {}
@@ -67,20 +90,49 @@ def gen_weights_hbm(torch, dims, layer_range, first, last, seed=1234):
             continue
         if len(shape) == 1:
             t = 1.0 + 0.1 * torch.randn(shape, device="cuda", dtype=torch.float32, generator=g)
-        else:
+            out[name] = (t, 0, 1, shape[0])
+            continue
+        ty = tensor_type(name, dims, quant)
+        if ty == 1:
             t = torch.empty(shape, device="cuda", dtype=torch.float16)
             rows = max(1, (1 << 26) // shape[1])
             for r0 in range(0, shape[0], rows):
                 r1 = min(shape[0], r0 + rows)
                 t[r0:r1] = (0.02 * torch.randn((r1 - r0, shape[1]), device="cuda", dtype=torch.float32, generator=g)).half()
-        out[name] = t
+        else:
+            nblk = shape[0] * shape[1] // 256
+            bb = 144 if ty == Q4_K else 210
+            t = torch.randint(0, 256, (nblk, bb), device="cuda", dtype=torch.uint8, generator=g)
+            if ty == Q4_K:
+                hdr = torch.tensor([1.0e-4, 8.0e-4], dtype=torch.float16).view(torch.uint8).to("cuda")
+                t[:, 0:4] = hdr
+            else:
+                t[:, 208:210] = torch.tensor([2.0e-5], dtype=torch.float16).view(torch.uint8).to("cuda")
+        out[name] = (t, ty, shape[0], shape[1])
     torch.cuda.synchronize()
     return out
 
 
 def as_model_tensors(_lib, weights):
-    return {k: (t.data_ptr(), _lib.F16 if t.dtype.itemsize == 2 else _lib.F32,
-                1 if t.dim() == 1 else t.shape[0], t.shape[-1]) for k, t in weights.items()}
+    return {k: (t.data_ptr(), ty, rows, cols) for k, (t, ty, rows, cols) in weights.items()}
+
+
+def host_weights(weights):
+    """Device tensors -> what the oracle takes: fp16 matrices stay fp16 (same operand values);
+    if any matrix is K-quantised, every matrix becomes its dequantised fp32 form."""
+    import oracle as orc
+    any_q = any(ty in (Q4_K, Q6_K) for _, ty, _, _ in weights.values())
+    host = {}
+    for k, (t, ty, rows, cols) in weights.items():
+        a = t.cpu().numpy()
+        if ty == Q4_K:
+            a = orc.dequant_q4k(a.reshape(-1), rows * cols).reshape(rows, cols)
+        elif ty == Q6_K:
+            a = orc.dequant_q6k(a.reshape(-1), rows * cols).reshape(rows, cols)
+        elif rows > 1 and any_q:
+            a = a.astype(np.float32)
+        host[k] = a
+    return host
 
 
 def cpu_baseline(args, dims, weights, first_token, gpu_logits0, n_tokens):
@@ -88,7 +140,7 @@ def cpu_baseline(args, dims, weights, first_token, gpu_logits0, n_tokens):
     output rows) timed on this box's host cores on a bounded sample of the SAME workload: the
     first `n_tokens` tokens of the same model from position 0 (weights identical to the GPU's)."""
     import oracle as orc
-    host = {k: t.cpu().numpy() for k, t in weights.items()}
+    host = host_weights(weights)
     C = n_tokens + 1
     desc = orc.LlamaDesc(E=dims.E, L=dims.L, H=dims.H, Hkv=dims.Hkv, D=dims.D, F=dims.F, V=dims.V, C=C)
     ref = orc.OracleLlama(desc, host)
@@ -116,7 +168,7 @@ def run_single(args):
 
     dims = synth.BY_NAME[args.model]
     torch.cuda.set_device(0)
-    weights = gen_weights_hbm(torch, dims, (0, dims.L), True, True)
+    weights = gen_weights_hbm(torch, dims, (0, dims.L), True, True, quant=args.quant)
     mgr = HipBufferManager(0)
     C = args.context + args.warmup + args.steps
     m = LlamaModel(mgr, synth.make_metadata(dims), as_model_tensors(_lib, weights), C,
@@ -162,13 +214,13 @@ def run_single(args):
         "value": value, "unit": "tokens/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{dims.name} fp16-GGUF weights (fp16 in HBM), fp32 activations + {'fp16' if args.kv_f16 else 'fp32'} KV, "
+        "config": {"workload": f"{dims.name} {'fp16-GGUF weights (fp16 in HBM)' if args.quant == 'f16' else 'Q4_K_M-GGUF weights (native K-quant blocks in HBM)'}, fp32 activations + {'fp16' if args.kv_f16 else 'fp32'} KV, "
                                f"batch-1 greedy decode of {args.steps} tokens after a {args.context}-token context",
                    "positions": [pos0, pos0 + args.steps - 1], "kv_capacity": C, "parallelism": "single",
                    "graph": not args.no_graph},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                     "kernel": "k_gemv<F16,GATEUP> (RMSNorm + Wgate/Wup GEMV + SiLU*up)",
+                     "kernel": ("k_gemv<F16,GATEUP>" if args.quant == "f16" else "k_gemv_kq<Q4_K,GATEUP>") + " (RMSNorm + Wgate/Wup GEMV + SiLU*up)",
                      "bytes_per_launch": dom_bytes, "us_per_launch": gu_ms * 1e3},
         "token_hbm_gbps": b_tok / (ms_per_step * 1e-3) / 1e9,
         "token_hbm_frac_of_peak": b_tok / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,

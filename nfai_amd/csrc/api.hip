@@ -317,7 +317,15 @@ NFAI_API int32_t nfai_hip_weight_upload(nfai_ctx_t h, int32_t type, uint64_t n_r
     if (rc) return rc;
     rc = nfai_hip_buf_alloc(h, bytes, out);
     if (rc) return rc;
-    return nfai_hip_buf_upload(h, *out, 0, host, bytes);
+    if (type != NFAI_Q6_K) return nfai_hip_buf_upload(h, *out, 0, host, bytes);
+    // Q6_K: 210-byte native blocks are repacked into the aligned plane layout the kernels read
+    nfai_buf_t tmp = 0;
+    if ((rc = nfai_hip_buf_alloc(h, bytes, &tmp))) return rc;
+    if ((rc = nfai_hip_buf_upload(h, tmp, 0, host, bytes))) return rc;
+    Ctx *c = ctx_of(h);
+    hipError_t e = launch_repack_q6k(buf_of(tmp)->ptr, buf_of(*out)->ptr, n_rows * n_cols / 256, c->stream);
+    if (e != hipSuccess) return fail(NFAI_ERR_HIP, "weight_upload: Q6_K repack failed: %s", hipGetErrorString(e));
+    return nfai_hip_buf_free(h, tmp);
 }
 
 // ---- 1:1 operators ---------------------------------------------------------------------------
@@ -332,9 +340,15 @@ NFAI_API int32_t nfai_hip_embed(nfai_ctx_t h, nfai_buf_t table, int32_t type, nf
     BUF_OR_FAIL(bt, table);
     BUF_OR_FAIL(bk, tok);
     BUF_OR_FAIL(by, y);
-    if (type != NFAI_F16 && type != NFAI_F32) return fail(NFAI_ERR_UNSUPPORTED, "embed: table type %d", type);
     NEED(bk, 1, 4);
     NEED(by, E, 4);
+    if (type == NFAI_Q4_K || type == NFAI_Q6_K) {
+        const uint64_t rb = weight_row_bytes(type, E);
+        if (rb == 0) return fail(NFAI_ERR_UNSUPPORTED, "embed: K-quant table needs E %% 256 == 0 (E=%u)", E);
+        LAUNCH_TRY(launch_embed_kq(bt->ptr, type, bt->bytes / rb, static_cast<const uint32_t *>(bk->ptr), static_cast<float *>(by->ptr), E, c->stream));
+        return NFAI_OK;
+    }
+    if (type != NFAI_F16 && type != NFAI_F32) return fail(NFAI_ERR_UNSUPPORTED, "embed: table type %d", type);
     LAUNCH_TRY(launch_embed(bt->ptr, type, static_cast<const uint32_t *>(bk->ptr), static_cast<float *>(by->ptr), E, c->stream));
     return NFAI_OK;
 }

@@ -86,7 +86,13 @@ struct GemvArgs {
 };
 enum GemvMode { GEMV_PLAIN = 0, GEMV_RESIDUAL = 1, GEMV_QKV_ROPE = 2, GEMV_GATEUP = 3 };
 
-hipError_t launch_gemv(const GemvArgs &a, hipStream_t s);
+hipError_t launch_gemv(const GemvArgs &a, hipStream_t s);     // any weight type; K-quants go to launch_gemv_kq
+hipError_t launch_gemv_kq(const GemvArgs &a, hipStream_t s);  // Q4_K (native blocks) / Q6_K (plane layout)
+// Q6_K super-blocks are 210 bytes (not 16-byte aligned): in HBM they live as four planes
+// ql | qh | scales | d (same bytes, naturally aligned accesses).  nblk = rows * cols / 256.
+hipError_t launch_repack_q6k(const void *native, void *planes, uint64_t nblk, hipStream_t s);
+hipError_t launch_embed_kq(const void *table, int type, uint64_t n_rows, const uint32_t *tok, float *y, uint32_t E,
+                           hipStream_t s);
 
 struct AttnArgs {
     const float *q = nullptr;  // [H][D] fp32 (after RoPE)

@@ -133,8 +133,8 @@ int check_shape(const char *what, const Tensor &t, uint64_t rows, uint64_t cols,
         return fail(NFAI_ERR_INVALID, "finalize: tensor %s is %llux%llu, expected %llux%llu", what, (unsigned long long)t.rows,
                     (unsigned long long)t.cols, (unsigned long long)rows, (unsigned long long)cols);
     if (!matrix && t.type != NFAI_F32) return fail(NFAI_ERR_UNSUPPORTED, "finalize: norm gain %s must be F32 (type %d)", what, t.type);
-    if (matrix && t.type != NFAI_F16 && t.type != NFAI_F32)
-        return fail(NFAI_ERR_UNSUPPORTED, "finalize: matrix %s has ggml type %d; kernels exist for F16/F32", what, t.type);
+    if (matrix && t.type != NFAI_F16 && t.type != NFAI_F32 && t.type != NFAI_Q4_K && t.type != NFAI_Q6_K)
+        return fail(NFAI_ERR_UNSUPPORTED, "finalize: matrix %s has ggml type %d; kernels exist for F16/F32/Q4_K/Q6_K", what, t.type);
     return NFAI_OK;
 }
 
@@ -193,18 +193,29 @@ int block_fused(Model *m, Layer &L, Rec &rec)
     const nfai_llama_desc &d = m->d;
     hipStream_t s = m->ctx->stream;
     {
-        GemvArgs a = gemv_base(m, L.wq, m->x, d.E);
-        a.W[1] = L.wk.ptr; a.W[2] = L.wv.ptr;
-        a.seg_rows[1] = (uint32_t)L.wk.rows; a.seg_rows[2] = (uint32_t)L.wv.rows;
-        a.gamma = static_cast<const float *>(L.attn_norm.ptr);
-        a.mode = GEMV_QKV_ROPE;
-        a.y = m->q;
-        a.kcache = L.kcache; a.vcache = L.vcache;
-        a.kv_type = m->kv_f16 ? NFAI_F16 : NFAI_F32;
-        a.kv_pos_stride = m->kv_pos_stride; a.kv_head_stride = m->kv_head_stride;
-        a.rope_cs = m->d_ropecs; a.rope_dims = d.rope_dims;
-        a.H = d.H; a.Hkv = d.Hkv; a.D = d.D;
-        K_TRY(KC_QKV, launch_gemv(a, s));
+        // One launch when q, k, v share an encoding; Q4_K_M files keep attn_v in Q6_K on some blocks:
+        // then the segments that differ get their own launch (same kernel family, same epilogue).
+        const Tensor *seg[3] = {&L.wq, &L.wk, &L.wv};
+        for (int first = 0; first < 3;) {
+            int last = first;
+            while (last + 1 < 3 && seg[last + 1]->type == seg[first]->type) last++;
+            GemvArgs a = gemv_base(m, *seg[first], m->x, d.E);
+            for (int i = 0; i < 3; i++) {
+                const bool in = i >= first && i <= last;
+                a.W[i] = in ? seg[i]->ptr : seg[first]->ptr;
+                a.seg_rows[i] = in ? (uint32_t)seg[i]->rows : 0;
+            }
+            a.gamma = static_cast<const float *>(L.attn_norm.ptr);
+            a.mode = GEMV_QKV_ROPE;
+            a.y = m->q;
+            a.kcache = L.kcache; a.vcache = L.vcache;
+            a.kv_type = m->kv_f16 ? NFAI_F16 : NFAI_F32;
+            a.kv_pos_stride = m->kv_pos_stride; a.kv_head_stride = m->kv_head_stride;
+            a.rope_cs = m->d_ropecs; a.rope_dims = d.rope_dims;
+            a.H = d.H; a.Hkv = d.Hkv; a.D = d.D;
+            K_TRY(KC_QKV, launch_gemv(a, s));
+            first = last + 1;
+        }
     }
     {
         AttnArgs a;
@@ -274,7 +285,10 @@ int enqueue_token(Model *m, bool with_head)
     hipStream_t s = m->ctx->stream;
     Rec rec{m};
     const uint32_t nfreq = (d.rope_dims < d.D ? d.rope_dims : d.D) / 2;
-    K_TRY(KC_OTHER, launch_token_begin(m->first_stage ? m->token_embd.ptr : nullptr, m->token_embd.type, m->d_tok, m->x, d.E,
+    const bool emb_kq = m->token_embd.type == NFAI_Q4_K || m->token_embd.type == NFAI_Q6_K;
+    if (m->first_stage && emb_kq)
+        K_TRY(KC_OTHER, launch_embed_kq(m->token_embd.ptr, m->token_embd.type, m->token_embd.rows, m->d_tok, m->x, d.E, s));
+    K_TRY(KC_OTHER, launch_token_begin(m->first_stage && !emb_kq ? m->token_embd.ptr : nullptr, m->token_embd.type, m->d_tok, m->x, d.E,
                                        m->d_freqs, m->d_ropecs, nfreq, m->d_pos, s));
     for (Layer &L : m->layers) {
         int rc = m->unfused ? block_unfused(m, L, rec) : block_fused(m, L, rec);
@@ -465,7 +479,21 @@ static int set_tensor_impl(Model *m, const char *name, int type, uint64_t rows, 
                              (unsigned long long)cols);
     if (t->owned && t->ptr) { HIP_TRY(hipFree(t->ptr)); }
     t->type = type; t->rows = rows; t->cols = cols; t->bytes = rb * rows;
-    if (dev) {
+    if (type == NFAI_Q6_K) {
+        // native 210-byte blocks (host or device) -> owned plane-layout copy (see common.h)
+        void *native = dev;
+        if (!dev) {
+            if (!host) return fail(NFAI_ERR_INVALID, "set_tensor(%s): null data", name);
+            DALLOC(native, t->bytes);
+            HIP_TRY(hipMemcpyAsync(native, host, t->bytes, hipMemcpyHostToDevice, m->ctx->stream));
+        }
+        DALLOC(t->ptr, t->bytes);
+        t->owned = true;
+        hipError_t e = launch_repack_q6k(native, t->ptr, rows * cols / 256, m->ctx->stream);
+        if (e != hipSuccess) return fail(NFAI_ERR_HIP, "set_tensor(%s): Q6_K repack failed: %s", name, hipGetErrorString(e));
+        HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+        if (!dev) HIP_TRY(hipFree(native));
+    } else if (dev) {
         if (reinterpret_cast<uintptr_t>(dev) & 15) return fail(NFAI_ERR_INVALID, "set_tensor_device(%s): pointer not 16-byte aligned", name);
         t->ptr = dev;
         t->owned = false;
@@ -520,10 +548,8 @@ NFAI_API int32_t nfai_hip_llama_finalize(nfai_model_t h)
         CHK(wup, "ffn_up.weight", d.F, d.E, true)
         CHK(wdown, "ffn_down.weight", d.E, d.F, true)
 #undef CHK
-        if (!m->unfused) {
-            if (L.wq.type != L.wk.type || L.wq.type != L.wv.type || L.wgate.type != L.wup.type)
-                return fail(NFAI_ERR_UNSUPPORTED, "finalize: blk.%zu mixes tensor types inside a fused group (q/k/v or gate/up)", i + d.layer_begin);
-        }
+        if (!m->unfused && L.wgate.type != L.wup.type)
+            return fail(NFAI_ERR_UNSUPPORTED, "finalize: blk.%zu ffn_gate and ffn_up have different tensor types", i + d.layer_begin);
     }
     if (m->graph_exec) { hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
     if (m->graph) { hipGraphDestroy(m->graph); m->graph = nullptr; }

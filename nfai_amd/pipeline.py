@@ -119,8 +119,7 @@ class HipStage:
         from .llama_model import LlamaModel
         self.torch, self.rank, self.world = torch, rank, world
         E = dims.E
-        tens = {k: (t.data_ptr(), _lib.F16 if t.dtype.itemsize == 2 else _lib.F32, 1 if t.dim() == 1 else t.shape[0],
-                    t.shape[-1]) for k, t in weights.items()}
+        tens = {k: (t.data_ptr(), ty, rows, cols) for k, (t, ty, rows, cols) in weights.items()}
         d = dict(E=dims.E, L=dims.L, H=dims.H, Hkv=dims.Hkv, D=dims.D, F=dims.F, V=dims.V, eps=1e-5, rope_dims=dims.D,
                  rope_base=500000.0)
         self.models = [LlamaModel(mgr, {"general.name": dims.name}, tens, capacity, layer_range=layer_range, dims=d,

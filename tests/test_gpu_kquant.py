@@ -1,0 +1,136 @@
+"""K-quant (Q4_K / Q6_K) decode path on the GPU against the oracle.
+
+The reference cannot load these tensor types (NFAI.GGUF/Parser.cs:111-114 throws), so parity is
+UNPINNED by the reference: the oracle here is "dequantise the blocks (ggml layout, restated in
+oracle/nfai_oracle.c) then the reference's fp32 GEMV".  Blocks come from the build's own quantisers
+(valid blocks with every field exercised; random-byte blocks are covered on the decode side in
+tests/test_oracle.py)."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from nfai_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+Q4_K, Q6_K = 12, 14
+
+
+@pytest.fixture(scope="module")
+def mgr():
+    from nfai_amd.hip import HipBufferManager
+    m = HipBufferManager(0)
+    yield m
+    m.Dispose()
+
+
+def rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def quantize(W, qt):
+    """W [N][K] fp32 -> (raw block bytes, dequantised fp32 [N][K])."""
+    N, K = W.shape
+    if qt == Q4_K:
+        b = orc.quantize_q4k(W)
+        return b, orc.dequant_q4k(b, N * K).reshape(N, K)
+    b = orc.quantize_q6k(W)
+    return b, orc.dequant_q6k(b, N * K).reshape(N, K)
+
+
+def tol(Wd, x):
+    s = np.abs(Wd.astype(np.float64)) @ np.abs(x.astype(np.float64))
+    return 2e-6 * np.sqrt(Wd.shape[1] / 256.0) * s + 1e-6
+
+
+@pytest.mark.parametrize("qt", [Q4_K, Q6_K])
+@pytest.mark.parametrize("N,K", [(2048, 2048), (1024, 3072), (512, 8192), (96, 256), (40, 768), (300, 14336), (7, 4096)])
+def test_gemv_kquant(mgr, qt, N, K):
+    from nfai_amd.shaders import MatrixMultiplyShader
+    r = rng(N + K + qt)
+    W = (0.02 * r.standard_normal((N, K))).astype(np.float32)
+    raw, Wd = quantize(W, qt)
+    x = r.standard_normal(K).astype(np.float32)
+    op = MatrixMultiplyShader(mgr, 1, K, N, None)
+    op.GetWeightProperty().set(raw, qt, N, K)
+    op.GetInputProperty().SetValue(x)
+    op.Compute()
+    ref = orc.gemv(Wd, x)
+    err = np.abs(op.GetOutputs() - ref)
+    assert (err <= tol(Wd, x)).all(), (err.max(), tol(Wd, x).min())
+
+
+@pytest.mark.parametrize("qt", [Q4_K, Q6_K])
+def test_embed_kquant(mgr, qt):
+    from nfai_amd._lib import call
+    from nfai_amd.hip import ShaderProperty
+    r = rng(qt)
+    V, E = 300, 768
+    W = (0.05 * r.standard_normal((V, E))).astype(np.float32)
+    raw, Wd = quantize(W, qt)
+    tab = mgr.UploadWeight(qt, raw, V, E)
+    tok, y = ShaderProperty(mgr, 1, np.uint32), ShaderProperty(mgr, E)
+    for t in (0, 1, 299, 123):
+        tok.SetValue(np.array([t], np.uint32))
+        call("nfai_hip_embed", mgr.handle, tab.handle, qt, tok.handle, y.handle, E)
+        np.testing.assert_allclose(y.GetValue(), Wd[t], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("qt", [Q4_K, Q6_K])
+@pytest.mark.parametrize("E,F", [(3072, 8192), (2048, 8192), (256, 512)])
+def test_gateup_and_residual_kquant(mgr, qt, E, F):
+    from nfai_amd._lib import call
+    from nfai_amd.hip import ShaderProperty
+    r = rng(E + F + qt)
+    Wg = (0.02 * r.standard_normal((F, E))).astype(np.float32)
+    Wu = (0.02 * r.standard_normal((F, E))).astype(np.float32)
+    Wd_ = (0.02 * r.standard_normal((E, F))).astype(np.float32)
+    (rg, dg), (ru, du), (rd, dd) = quantize(Wg, qt), quantize(Wu, qt), quantize(Wd_, qt)
+    x = r.standard_normal(E).astype(np.float32)
+    g = (1 + 0.1 * r.standard_normal(E)).astype(np.float32)
+    pg_, pu, pd = mgr.UploadWeight(qt, rg, F, E), mgr.UploadWeight(qt, ru, F, E), mgr.UploadWeight(qt, rd, E, F)
+    px, pg, pa, py = ShaderProperty(mgr, E), ShaderProperty(mgr, E), ShaderProperty(mgr, F), ShaderProperty(mgr, E)
+    px.SetValue(x); pg.SetValue(g)
+    call("nfai_hip_gemv_gateup_silu", mgr.handle, pg_.handle, pu.handle, qt, px.handle, pg.handle, 1e-5, pa.handle, F, E)
+    xn = orc.rmsnorm(x, g, 1e-5)
+    act = orc.mul(orc.gemv(du, xn), orc.silu(orc.gemv(dg, xn)))
+    np.testing.assert_allclose(pa.GetValue(), act, rtol=1e-4, atol=2e-5)
+    call("nfai_hip_gemv_fused", mgr.handle, pd.handle, qt, pa.handle, 0, 0.0, px.handle, py.handle, E, F)
+    want = orc.add(x, orc.gemv(dd, pa.GetValue()))
+    assert (np.abs(py.GetValue() - want) <= tol(dd, pa.GetValue()) + 1e-5).all()
+
+
+@pytest.mark.parametrize("vq", [Q4_K, Q6_K])
+def test_qkv_rope_kquant_mixed_v(mgr, vq):
+    """q, k in Q4_K with v in Q4_K or Q6_K (the Q4_K_M mix): through the model path, which splits the
+    launch when the encodings differ."""
+    from nfai_amd.llama_model import LlamaModel, QuantTensor
+    dims = synth.TINY_D128
+    w = synth.make_weights(dims, seed=61, std=0.05)
+    wq, wref = {}, {}
+    for name, a in w.items():
+        if a.ndim == 1:
+            wq[name] = a
+            wref[name] = a
+            continue
+        qt = Q6_K if (name.endswith(("attn_v.weight", "ffn_down.weight")) and vq == Q6_K) or name.startswith(("token_embd", "output.")) else Q4_K
+        raw, deq = quantize(a.astype(np.float32), qt)
+        wq[name] = QuantTensor(raw, qt, a.shape)
+        wref[name] = deq
+    md = synth.make_metadata(dims)
+    dd = dict(E=dims.E, L=dims.L, H=dims.H, Hkv=dims.Hkv, D=dims.D, F=dims.F, V=dims.V, eps=1e-5, rope_dims=dims.D, rope_base=500000.0)
+    m = LlamaModel(mgr, md, wq, 40, dims=dd)
+    mu = LlamaModel(mgr, md, wq, 40, dims=dd, unfused=True)
+    ref = orc.OracleLlama(orc.LlamaDesc(E=dims.E, L=dims.L, H=dims.H, Hkv=dims.Hkv, D=dims.D, F=dims.F, V=dims.V, C=40), wref)
+    for i, t in enumerate(synth.make_tokens(dims, 32, seed=9)):
+        lg, am = m.Step(int(t))
+        lu, _ = mu.Step(int(t))
+        want = ref.step(int(t))
+        scale = max(1.0, float(np.abs(want).max()))
+        assert np.abs(lg - want).max() <= 2e-3 * scale, (i, np.abs(lg - want).max())
+        assert np.abs(lu - want).max() <= 2e-3 * scale
+        assert am == orc.argmax(want)
+    total, _ = m.BytesPerToken(0)
+    assert total < sum(a.nbytes for a in w.values() if a.ndim == 2) * 0.45  # 4.5-6.6 bits instead of 16
+    m.Dispose()
+    mu.Dispose()
