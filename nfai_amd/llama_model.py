@@ -95,6 +95,9 @@ class LlamaModel:
         d = dims or dims_from_metadata(metadata, tensors)
         self.dims = d
         self.ModelName = str(metadata.get("general.name", "unknown"))
+        if tokenizer is None and "tokenizer.ggml.tokens" in metadata and "tokenizer.ggml.merges" in metadata:
+            from .tokenizer import Tokenizer
+            tokenizer = Tokenizer(metadata)  # LlamaModel.cs:41
         self.tokenizer = tokenizer
         self.firstInput = True
         lb, le = layer_range or (0, d["L"])

