@@ -1,0 +1,342 @@
+// kernels_prefill.hip — batched prompt ingestion on the matrix cores.
+//
+// The reference has no batched prefill: the prompt goes through the M = 1 GEMV path token by token
+// (LlamaModel.cs:103-126; every MatrixMultiplyShader is built with inputRowCount = 1,
+// TransformerBlock.cs:47-101).  Here T prompt tokens go through each block together: the seven
+// projections become [T x K] x [N x K]^T GEMMs on v_mfma_f32_16x16x32_f16 (fp16 operands, fp32
+// accumulate), attention becomes two batched GEMMs around a causal row softmax.  Oracle = the
+// reference's token-by-token fp32 path; tolerance is the "stated fp16 tolerance" (activations are
+// rounded to fp16 on the way into the MFMA): logits max|d| <= 5e-2, same argmax (tests).
+//
+// GEMM  C[M][N] (+R) = A[M][K] * B[N][K]^T      (B = GGUF weight matrix as stored: K contiguous)
+//   bound: MFMA for M = 512 (2*M*N*K flop over (M + N)*K*2 B of operands), HBM for small M.
+//   tile 128 x 64 x 64, 256 threads = 4 waves stacked on M (32 rows x 64 cols each = 2 x 4 MFMA
+//   tiles, 16 MFMAs per wave per K tile); operands staged global -> VGPR -> LDS (two buffers, the
+//   next tile's global loads are in flight during the MFMAs, one barrier per K tile); LDS rows are
+//   128 B with the 16-byte chunk index XOR (row & 7) so the ds_read_b128 fragment reads of 16 rows
+//   at one k-chunk spread over 8 bank groups; A may be fp32 in memory (converted while staging).
+//   blockIdx -> (m tile, n tile) is XCD-aware: the m tiles that share a weight tile get ids that are
+//   equal mod 8 (same XCD, adjacent dispatch slots), so a weight tile is read from HBM once and from
+//   that XCD's L2 by the other m tiles.
+#include "common.h"
+
+namespace nfai {
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GBM = 128, GBN = 64, GBK = 64, GTHREADS = 256;
+
+struct GemmParams {
+    const void *A;          // [M][lda] fp16 or fp32
+    const _Float16 *B;      // [N][ldb] fp16
+    float *C;               // [M][ldc] fp32
+    const float *R;         // optional residual [M][ldc]
+    uint32_t M, N, K, lda, ldb, ldc;
+    uint64_t a_bs, b_bs, c_bs;   // batch strides (elements)
+    uint32_t b_div;              // B batch index = batch / b_div (GQA: query heads share a kv head)
+    float alpha;
+};
+
+__device__ __forceinline__ uint32_t lds_off(uint32_t row, uint32_t chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+template <bool A_F32>
+__global__ __launch_bounds__(GTHREADS) void k_gemm_f16(const GemmParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * (GBM + GBN) * 128];
+    auto ldsA = [&](int buf) -> uint8_t * { return lds + buf * (GBM + GBN) * 128; };
+    auto ldsB = [&](int buf) -> uint8_t * { return lds + buf * (GBM + GBN) * 128 + GBM * 128; };
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tiles_m = (p.M + GBM - 1) / GBM, tiles_n = p.N / GBN;
+    uint32_t mt_i, nt_i;
+    {
+        const uint32_t id = blockIdx.x;
+        if (tiles_n % 8 == 0) {
+            const uint32_t xcd = id & 7, slot = id >> 3;
+            nt_i = (slot / tiles_m) * 8 + xcd;
+            mt_i = slot % tiles_m;
+        } else {
+            nt_i = id / tiles_m;
+            mt_i = id % tiles_m;
+        }
+    }
+    const uint32_t m0 = mt_i * GBM, n0 = nt_i * GBN, batch = blockIdx.y;
+    const uint8_t *Ab = static_cast<const uint8_t *>(p.A) + (uint64_t)batch * p.a_bs * (A_F32 ? 4 : 2);
+    const _Float16 *Bb = p.B + (uint64_t)(batch / p.b_div) * p.b_bs;
+    float *Cb = p.C + (uint64_t)batch * p.c_bs;
+    const float *Rb = p.R ? p.R + (uint64_t)batch * p.c_bs : nullptr;
+
+    // staging registers: A 128x64 halves = 1024 16-byte chunks (4 per thread) — or, from fp32, 2048
+    // 16-byte loads of 4 floats (8 per thread); B 64x64 halves = 512 chunks (2 per thread)
+    constexpr int AN = A_F32 ? 8 : 4;
+    u32x4 ra[AN], rb[2];
+    auto load_tile = [&](uint32_t kt) {
+        const uint32_t k0 = kt * GBK;
+#pragma unroll
+        for (int i = 0; i < AN; i++) {
+            const uint32_t c = tid + i * GTHREADS;
+            if constexpr (A_F32) {
+                const uint32_t row = c >> 4, q = c & 15;  // 16 float4 per row
+                const uint32_t gr = min(m0 + row, p.M - 1);
+                ra[i] = *reinterpret_cast<const GLOBAL_AS u32x4 *>((const GLOBAL_AS uint8_t *)Ab + ((uint64_t)gr * p.lda + k0 + q * 4) * 4);
+            } else {
+                const uint32_t row = c >> 3, q = c & 7;   // 8 chunks of 8 halves per row
+                const uint32_t gr = min(m0 + row, p.M - 1);
+                ra[i] = *reinterpret_cast<const GLOBAL_AS u32x4 *>((const GLOBAL_AS uint8_t *)Ab + ((uint64_t)gr * p.lda + k0 + q * 8) * 2);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t c = tid + i * GTHREADS, row = c >> 3, q = c & 7;
+            rb[i] = *reinterpret_cast<const GLOBAL_AS u32x4 *>((const GLOBAL_AS uint8_t *)Bb + ((uint64_t)(n0 + row) * p.ldb + k0 + q * 8) * 2);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AN; i++) {
+            const uint32_t c = tid + i * GTHREADS;
+            if constexpr (A_F32) {
+                const uint32_t row = c >> 4, q = c & 15;
+                const f32x4 v = __builtin_bit_cast(f32x4, ra[i]);
+                const f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                *reinterpret_cast<f16x4 *>(ldsA(buf) + lds_off(row, q >> 1) + (q & 1) * 8) = h;
+            } else {
+                const uint32_t row = c >> 3, q = c & 7;
+                *reinterpret_cast<u32x4 *>(ldsA(buf) + lds_off(row, q)) = ra[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t c = tid + i * GTHREADS, row = c >> 3, q = c & 7;
+            *reinterpret_cast<u32x4 *>(ldsB(buf) + lds_off(row, q)) = rb[i];
+        }
+    };
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const uint32_t KT = p.K / GBK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (uint32_t kt = 0; kt < KT; kt++) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) load_tile(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const uint32_t chunk = ks * 4 + (lane >> 4);
+            f16x8 af[2], bf[4];
+#pragma unroll
+            for (int i = 0; i < 2; i++) af[i] = *reinterpret_cast<const f16x8 *>(ldsA(cur) + lds_off(wave * 32 + i * 16 + (lane & 15), chunk));
+#pragma unroll
+            for (int j = 0; j < 4; j++) bf[j] = *reinterpret_cast<const f16x8 *>(ldsB(cur) + lds_off(j * 16 + (lane & 15), chunk));
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < KT) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // C/D layout of mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t row = m0 + wave * 32 + i * 16 + (lane >> 4) * 4 + r, col = n0 + j * 16 + (lane & 15);
+                if (row < p.M) {
+                    float v = acc[i][j][r] * p.alpha;
+                    if (Rb) v += Rb[(uint64_t)row * p.ldc + col];
+                    Cb[(uint64_t)row * p.ldc + col] = v;
+                }
+            }
+}
+
+hipError_t launch_gemm_f16(const GemmArgs &a, hipStream_t s)
+{
+    if (a.M == 0 || a.N == 0) return hipSuccess;
+    if (a.N % GBN != 0 || a.K % GBK != 0 || a.K == 0) return hipErrorInvalidValue;
+    if (a.lda % 8 != 0 || a.ldb % 8 != 0) return hipErrorInvalidValue;
+    GemmParams p{};
+    p.A = a.A; p.B = static_cast<const _Float16 *>(a.B); p.C = a.C; p.R = a.R;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldb = a.ldb; p.ldc = a.ldc;
+    p.a_bs = a.a_bs; p.b_bs = a.b_bs; p.c_bs = a.c_bs; p.b_div = a.b_div ? a.b_div : 1; p.alpha = a.alpha;
+    const uint32_t tiles = ((a.M + GBM - 1) / GBM) * (a.N / GBN);
+    const dim3 grid(tiles, a.batch ? a.batch : 1);
+    if (a.a_f32) hipLaunchKernelGGL((k_gemm_f16<true>), grid, dim3(GTHREADS), 0, s, p);
+    else hipLaunchKernelGGL((k_gemm_f16<false>), grid, dim3(GTHREADS), 0, s, p);
+    return hipGetLastError();
+}
+
+// ---- row-batched small ops ------------------------------------------------------------------------
+// RMSNormShader over T rows, output fp16 (the next GEMM's A operand).  One block per row.
+__global__ __launch_bounds__(256) void k_rmsnorm_rows(const float *x, const float *g, _Float16 *y, uint32_t E, float eps)
+{
+    __shared__ float red[16];
+    const float *xr = x + (uint64_t)blockIdx.x * E;
+    _Float16 *yr = y + (uint64_t)blockIdx.x * E;
+    float ss = 0.f;
+    for (uint32_t i = threadIdx.x; i < E; i += blockDim.x) ss = fmaf(xr[i], xr[i], ss);
+    ss = block_sum(ss, red);
+    const float rms = sqrtf(ss / (float)E + eps);
+    for (uint32_t i = threadIdx.x; i < E; i += blockDim.x) yr[i] = (_Float16)((xr[i] / rms) * g[i]);
+}
+
+hipError_t launch_rmsnorm_rows(const float *x, const float *g, void *y_f16, uint32_t T, uint32_t E, float eps, hipStream_t s)
+{
+    k_rmsnorm_rows<<<T, 256, 0, s>>>(x, g, static_cast<_Float16 *>(y_f16), E, eps);
+    return hipGetLastError();
+}
+
+// RoPE on T rows of q (-> fp16) and k (-> KV cache rows pos0+t), v -> cache rows.  One thread per pair.
+__global__ void k_rope_store_rows(const float *q, const float *k, const float *v, _Float16 *qh, void *kc, void *vc, int kv_f16,
+                                  uint64_t pos_stride, uint64_t head_stride, const float *freqs, uint32_t rope_dims, uint32_t H,
+                                  uint32_t Hkv, uint32_t D, uint32_t pos0)
+{
+    const uint32_t t = blockIdx.y, half = D / 2;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nq = H * half, nk = Hkv * half;
+    if (idx >= nq + 2 * nk) return;
+    const uint32_t pos = pos0 + t;
+    const uint32_t which = idx < nq ? 0u : (idx < nq + nk ? 1u : 2u);
+    const uint32_t li = which == 0 ? idx : (which == 1 ? idx - nq : idx - nq - nk);
+    const uint32_t h = li / half, pair = (li % half) * 2;
+    const float *src = which == 0 ? q + (uint64_t)t * H * D : (which == 1 ? k + (uint64_t)t * Hkv * D : v + (uint64_t)t * Hkv * D);
+    const float a = src[h * D + pair], b = src[h * D + pair + 1];
+    float o0 = a, o1 = b;
+    if (which < 2 && pair < rope_dims) {
+        const float theta = freqs[pair / 2] * (float)pos;
+        const float c = cosf(theta), sn = sinf(theta);
+        o0 = c * a - sn * b;
+        o1 = sn * a + c * b;
+    }
+    if (which == 0) {
+        qh[(uint64_t)t * H * D + h * D + pair] = (_Float16)o0;
+        qh[(uint64_t)t * H * D + h * D + pair + 1] = (_Float16)o1;
+    } else {
+        void *base = which == 1 ? kc : vc;
+        const uint64_t o = (uint64_t)pos * pos_stride + (uint64_t)h * head_stride + pair;
+        if (kv_f16) {
+            reinterpret_cast<_Float16 *>(base)[o] = (_Float16)o0;
+            reinterpret_cast<_Float16 *>(base)[o + 1] = (_Float16)o1;
+        } else {
+            reinterpret_cast<float *>(base)[o] = o0;
+            reinterpret_cast<float *>(base)[o + 1] = o1;
+        }
+    }
+}
+
+hipError_t launch_rope_store_rows(const float *q, const float *k, const float *v, void *qh, void *kc, void *vc, int kv_f16,
+                                  uint64_t pos_stride, uint64_t head_stride, const float *freqs, uint32_t rope_dims, uint32_t H,
+                                  uint32_t Hkv, uint32_t D, uint32_t pos0, uint32_t T, hipStream_t s)
+{
+    const uint32_t n = (H + 2 * Hkv) * D / 2;
+    k_rope_store_rows<<<dim3((n + 255) / 256, T), 256, 0, s>>>(q, k, v, static_cast<_Float16 *>(qh), kc, vc, kv_f16, pos_stride,
+                                                               head_stride, freqs, rope_dims, H, Hkv, D, pos0);
+    return hipGetLastError();
+}
+
+// KV cache (fp32 or fp16, strided) -> fp16 K [Hkv][Spad][D] and V^T [Hkv][D][Spad] for positions < S
+// (rows S..Spad-1 / columns S..Spad-1 are zero so the padded GEMMs see zeros).
+__global__ void k_kv_to_f16(const void *kc, const void *vc, int kv_f16, uint64_t pos_stride, uint64_t head_stride, _Float16 *kh,
+                            _Float16 *vt, uint32_t Hkv, uint32_t D, uint32_t S, uint32_t Spad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t n = (uint64_t)Hkv * Spad * D;
+    if (i >= n) return;
+    const uint32_t d = i % D, sp = (i / D) % Spad, h = i / ((uint64_t)D * Spad);
+    float kvv = 0.f, vvv = 0.f;
+    if (sp < S) {
+        const uint64_t o = (uint64_t)sp * pos_stride + (uint64_t)h * head_stride + d;
+        if (kv_f16) {
+            kvv = (float)reinterpret_cast<const _Float16 *>(kc)[o];
+            vvv = (float)reinterpret_cast<const _Float16 *>(vc)[o];
+        } else {
+            kvv = reinterpret_cast<const float *>(kc)[o];
+            vvv = reinterpret_cast<const float *>(vc)[o];
+        }
+    }
+    kh[i] = (_Float16)kvv;
+    vt[((uint64_t)h * D + d) * Spad + sp] = (_Float16)vvv;
+}
+
+hipError_t launch_kv_to_f16(const void *kc, const void *vc, int kv_f16, uint64_t pos_stride, uint64_t head_stride, void *kh, void *vt,
+                            uint32_t Hkv, uint32_t D, uint32_t S, uint32_t Spad, hipStream_t s)
+{
+    const uint64_t n = (uint64_t)Hkv * Spad * D;
+    k_kv_to_f16<<<(uint32_t)((n + 255) / 256), 256, 0, s>>>(kc, vc, kv_f16, pos_stride, head_stride, static_cast<_Float16 *>(kh),
+                                                            static_cast<_Float16 *>(vt), Hkv, D, S, Spad);
+    return hipGetLastError();
+}
+
+// causal softmax of one score row: query t (absolute position pos0 + t) attends keys 0..pos0+t.
+// scores [H][T][Spad] fp32 (unscaled dot products) -> P fp16, zero beyond the causal limit.
+// AttentionSoftmaxShader.cs:148-177 semantics (max, exp(clamp(.,-80,80)), sum, 1/sum).
+__global__ __launch_bounds__(256) void k_softmax_causal_rows(const float *sc, _Float16 *p, uint32_t T, uint32_t Spad, uint32_t pos0,
+                                                             float scale)
+{
+    __shared__ float red[16];
+    const uint32_t t = blockIdx.x % T;
+    const float *row = sc + (uint64_t)blockIdx.x * Spad;
+    _Float16 *prow = p + (uint64_t)blockIdx.x * Spad;
+    const uint32_t n = pos0 + t + 1;
+    float m = -1.0e38f;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, row[i] * scale);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) sum += expf(fminf(fmaxf(row[i] * scale - m, -80.f), 80.f));
+    sum = block_sum(sum, red);
+    const float inv = 1.0f / sum;
+    for (uint32_t i = threadIdx.x; i < Spad; i += blockDim.x)
+        prow[i] = i < n ? (_Float16)(expf(fminf(fmaxf(row[i] * scale - m, -80.f), 80.f)) * inv) : (_Float16)0.f;
+}
+
+hipError_t launch_softmax_causal_rows(const float *sc, void *p_f16, uint32_t H, uint32_t T, uint32_t Spad, uint32_t pos0, float scale,
+                                      hipStream_t s)
+{
+    k_softmax_causal_rows<<<H * T, 256, 0, s>>>(sc, static_cast<_Float16 *>(p_f16), T, Spad, pos0, scale);
+    return hipGetLastError();
+}
+
+// act = up * silu(gate) over T*F elements, fp16 out (SiLUShader + ElementWiseMultiplicationShader)
+__global__ void k_silu_mul_rows(const float *gate, const float *up, _Float16 *act, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) act[i] = (_Float16)(up[i] * silu_ref(gate[i]));
+}
+
+hipError_t launch_silu_mul_rows(const float *gate, const float *up, void *act_f16, uint64_t n, hipStream_t s)
+{
+    k_silu_mul_rows<<<(uint32_t)((n + 255) / 256), 256, 0, s>>>(gate, up, static_cast<_Float16 *>(act_f16), n);
+    return hipGetLastError();
+}
+
+// embedding rows for T tokens (device token ids) -> fp32 [T][E]
+__global__ void k_embed_rows(const void *table, int type, const uint32_t *toks, float *x, uint32_t E)
+{
+    const uint32_t t = blockIdx.y, d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= E) return;
+    const uint64_t row = (uint64_t)toks[t] * E;
+    x[(uint64_t)t * E + d] = type == NFAI_F16 ? (float)reinterpret_cast<const _Float16 *>(table)[row + d]
+                                              : reinterpret_cast<const float *>(table)[row + d];
+}
+
+hipError_t launch_embed_rows(const void *table, int type, const uint32_t *toks, float *x, uint32_t T, uint32_t E, hipStream_t s)
+{
+    k_embed_rows<<<dim3((E + 255) / 256, T), 256, 0, s>>>(table, type, toks, x, E);
+    return hipGetLastError();
+}
+
+}  // namespace nfai

@@ -11,6 +11,8 @@
 // dispatches and two host read-back/add/upload round trips per block)
 #include <string.h>
 
+#include <algorithm>
+
 #include <map>
 #include <string>
 #include <vector>
@@ -59,6 +61,13 @@ struct Model {
     // extra activations of the unfused 1:1 chain
     float *xn = nullptr, *qraw = nullptr, *scores = nullptr, *wts = nullptr, *proj = nullptr, *gate = nullptr, *up = nullptr;
     uint32_t *h_pin = nullptr;  // pinned staging for token / pos
+    // prefill workspace (allocated when desc.max_batch > 0); T = max_batch rounded up to 128
+    struct Prefill {
+        uint32_t T = 0, Spad = 0;
+        uint32_t *toks = nullptr;
+        float *X = nullptr, *H1 = nullptr, *Q = nullptr, *K = nullptr, *V = nullptr, *ATT = nullptr, *G = nullptr, *U = nullptr, *SC = nullptr;
+        void *XN = nullptr, *QH = nullptr, *KH = nullptr, *VT = nullptr, *P = nullptr, *ACT = nullptr;  // fp16
+    } pf;
     uint32_t pos_host = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
@@ -426,6 +435,28 @@ NFAI_API int32_t nfai_hip_llama_create(nfai_ctx_t ch, const nfai_llama_desc *des
         DALLOC(m->up, d.F * 4);
     }
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&m->h_pin), 4096, hipHostMallocDefault));
+    if (d.max_batch > 0 && !m->unfused) {
+        Model::Prefill &w = m->pf;
+        w.T = (d.max_batch + 127) / 128 * 128;
+        w.Spad = (d.C + 63) / 64 * 64;
+        const size_t T = w.T, HD = (size_t)d.H * d.D, KD = (size_t)d.Hkv * d.D;
+        DALLOC(w.toks, T * 4);
+        DALLOC(w.X, T * d.E * 4);
+        DALLOC(w.H1, T * d.E * 4);
+        DALLOC(w.Q, T * HD * 4);
+        DALLOC(w.K, T * KD * 4);
+        DALLOC(w.V, T * KD * 4);
+        DALLOC(w.ATT, T * HD * 4);
+        DALLOC(w.G, T * d.F * 4);
+        DALLOC(w.U, T * d.F * 4);
+        DALLOC(w.SC, (size_t)d.H * T * w.Spad * 4);
+        DALLOC(w.XN, T * std::max<size_t>(d.E, HD) * 2);
+        DALLOC(w.QH, T * HD * 2);
+        DALLOC(w.KH, KD * w.Spad * 2);
+        DALLOC(w.VT, KD * w.Spad * 2);
+        DALLOC(w.P, (size_t)d.H * T * w.Spad * 2);
+        DALLOC(w.ACT, T * d.F * 2);
+    }
     // RoPE frequency table as TransformerBlock.cs:33-38 builds it; entries >= rope_n_freqs are zero
     // (the reference uploads 32 entries only, TransformerBlock.cs:66).
     std::vector<float> fr(d.D / 2 + 8, 0.f);
@@ -459,6 +490,9 @@ NFAI_API int32_t nfai_hip_llama_destroy(nfai_model_t h)
     void *ptrs[] = {m->d_pos, m->d_tok, m->d_ring, m->d_freqs, m->d_ropecs, m->d_argmax_part, m->d_attn_part, m->x, m->h,
                     m->q, m->att, m->act, m->logits, m->xn, m->qraw, m->scores, m->wts, m->proj, m->gate, m->up};
     for (void *p : ptrs) if (p) hipFree(p);
+    void *pfp[] = {m->pf.toks, m->pf.X, m->pf.H1, m->pf.Q, m->pf.K, m->pf.V, m->pf.ATT, m->pf.G, m->pf.U, m->pf.SC,
+                   m->pf.XN, m->pf.QH, m->pf.KH, m->pf.VT, m->pf.P, m->pf.ACT};
+    for (void *p : pfp) if (p) hipFree(p);
     if (m->h_pin) hipHostFree(m->h_pin);
     m->magic = 0;
     handle_unregister(m);
@@ -618,17 +652,120 @@ NFAI_API int32_t nfai_hip_llama_decode_greedy(nfai_model_t h, uint32_t first_tok
     return nfai_hip_llama_fetch_tokens(h, n_steps, tokens_out);
 }
 
+// One chunk of T prompt tokens through every block on the MFMA path (kernels_prefill.hip).
+static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
+{
+    const nfai_llama_desc &d = m->d;
+    Model::Prefill &w = m->pf;
+    hipStream_t s = m->ctx->stream;
+    const uint32_t pos0 = m->pos_host, S = pos0 + T, Spad = (S + 63) / 64 * 64, HD = d.H * d.D, KD = d.Hkv * d.D;
+    const uint32_t G = d.H / d.Hkv;
+    const int kvf16 = m->kv_f16 ? 1 : 0;
+#define P_TRY(expr)                                                                                               \
+    do {                                                                                                          \
+        hipError_t _e = (expr);                                                                                   \
+        if (_e != hipSuccess)                                                                                     \
+            return fail(_e == hipErrorInvalidValue ? NFAI_ERR_INVALID : NFAI_ERR_HIP, "prefill: %s failed: %s", #expr, \
+                        hipGetErrorString(_e));                                                                   \
+    } while (0)
+    auto gemm = [&](const void *A, bool a_f32, uint32_t lda, const Tensor &W, float *C, const float *R, uint32_t N, uint32_t K) {
+        GemmArgs g;
+        g.A = A; g.a_f32 = a_f32; g.lda = lda; g.B = W.ptr; g.ldb = K; g.C = C; g.R = R; g.ldc = N;
+        g.M = T; g.N = N; g.K = K;
+        return launch_gemm_f16(g, s);
+    };
+    HIP_TRY(hipMemcpyAsync(w.toks, tokens, (size_t)T * 4, hipMemcpyHostToDevice, s));
+    P_TRY(launch_embed_rows(m->token_embd.ptr, m->token_embd.type, w.toks, w.X, T, d.E, s));
+    for (Layer &L : m->layers) {
+        P_TRY(launch_rmsnorm_rows(w.X, static_cast<const float *>(L.attn_norm.ptr), w.XN, T, d.E, d.eps, s));
+        P_TRY(gemm(w.XN, false, d.E, L.wq, w.Q, nullptr, HD, d.E));
+        P_TRY(gemm(w.XN, false, d.E, L.wk, w.K, nullptr, KD, d.E));
+        P_TRY(gemm(w.XN, false, d.E, L.wv, w.V, nullptr, KD, d.E));
+        P_TRY(launch_rope_store_rows(w.Q, w.K, w.V, w.QH, L.kcache, L.vcache, kvf16, m->kv_pos_stride, m->kv_head_stride, m->d_freqs,
+                                     d.rope_dims, d.H, d.Hkv, d.D, pos0, T, s));
+        P_TRY(launch_kv_to_f16(L.kcache, L.vcache, kvf16, m->kv_pos_stride, m->kv_head_stride, w.KH, w.VT, d.Hkv, d.D, S, Spad, s));
+        {   // scores[h][t][s] = q_h[t] . k_kvh[s]   (scaling and the causal limit are applied by the softmax)
+            GemmArgs g;
+            g.A = w.QH; g.lda = HD; g.a_bs = d.D;
+            g.B = w.KH; g.ldb = d.D; g.b_bs = (uint64_t)Spad * d.D; g.b_div = G;
+            g.C = w.SC; g.ldc = Spad; g.c_bs = (uint64_t)T * Spad;
+            g.M = T; g.N = Spad; g.K = d.D; g.batch = d.H;
+            P_TRY(launch_gemm_f16(g, s));
+        }
+        P_TRY(launch_softmax_causal_rows(w.SC, w.P, d.H, T, Spad, pos0, 1.0f / sqrtf((float)d.D), s));
+        {   // att[t][h*D + d] = sum_s P[h][t][s] * V_kvh[s][d]
+            GemmArgs g;
+            g.A = w.P; g.lda = Spad; g.a_bs = (uint64_t)T * Spad;
+            g.B = w.VT; g.ldb = Spad; g.b_bs = (uint64_t)d.D * Spad; g.b_div = G;
+            g.C = w.ATT; g.ldc = HD; g.c_bs = d.D;
+            g.M = T; g.N = d.D; g.K = Spad; g.batch = d.H;
+            P_TRY(launch_gemm_f16(g, s));
+        }
+        P_TRY(gemm(w.ATT, true, HD, L.wo, w.H1, w.X, d.E, HD));                       // + residual (TransformerBlock.cs:153-158)
+        P_TRY(launch_rmsnorm_rows(w.H1, static_cast<const float *>(L.ffn_norm.ptr), w.XN, T, d.E, d.eps, s));
+        P_TRY(gemm(w.XN, false, d.E, L.wgate, w.G, nullptr, d.F, d.E));
+        P_TRY(gemm(w.XN, false, d.E, L.wup, w.U, nullptr, d.F, d.E));
+        P_TRY(launch_silu_mul_rows(w.G, w.U, w.ACT, (uint64_t)T * d.F, s));
+        P_TRY(gemm(w.ACT, false, d.F, L.wdown, w.X, w.H1, d.E, d.F));                  // + residual (:176-181)
+    }
+#undef P_TRY
+    // the last token's hidden state continues on the M = 1 path (output norm + lm_head + argmax)
+    HIP_TRY(hipMemcpyAsync(m->x, w.X + (size_t)(T - 1) * d.E, (size_t)d.E * 4, hipMemcpyDeviceToDevice, s));
+    const uint32_t newpos = pos0 + T;
+    HIP_TRY(hipMemcpyAsync(m->d_pos, &newpos, 4, hipMemcpyHostToDevice, s));
+    m->pos_host = newpos;
+    return NFAI_OK;
+}
+
+static bool prefill_mfma_ok(const Model *m)
+{
+    if (m->pf.T == 0 || m->unfused || !(m->first_stage && m->last_stage)) return false;
+    const nfai_llama_desc &d = m->d;
+    if (d.E % 64 || d.F % 64 || (d.H * d.D) % 64 || (d.Hkv * d.D) % 64) return false;
+    if (m->token_embd.type != NFAI_F16 && m->token_embd.type != NFAI_F32) return false;
+    for (const Layer &L : m->layers)
+        for (const Tensor *t : {&L.wq, &L.wk, &L.wv, &L.wo, &L.wgate, &L.wup, &L.wdown})
+            if (t->type != NFAI_F16) return false;
+    return true;
+}
+
 NFAI_API int32_t nfai_hip_llama_prefill(nfai_model_t h, const uint32_t *tokens, uint32_t n, float *logits_last_host)
 {
     MODEL_OR_FAIL(m, h);
     NEED_FINAL(m);
     if (!tokens || n == 0) return fail(NFAI_ERR_INVALID, "prefill: empty prompt");
-    // Round 1: the prompt goes through the M = 1 path token by token, exactly as the reference
-    // feeds it (LlamaModel.cs:103-126); the batched MFMA path replaces this loop.
-    for (uint32_t i = 0; i < n; i++) {
-        int rc = nfai_hip_llama_decode_step(h, tokens[i], i + 1 == n ? logits_last_host : nullptr, nullptr);
-        if (rc) return rc;
+    if (m->pos_host + n > m->d.C) return fail(NFAI_ERR_KV_FULL, "prefill: %u tokens from position %u exceed KV capacity %u", n, m->pos_host, m->d.C);
+    for (uint32_t i = 0; i < n; i++)
+        if (tokens[i] >= m->d.V) return fail(NFAI_ERR_INVALID, "prefill: token %u >= vocab %u", tokens[i], m->d.V);
+    if (!prefill_mfma_ok(m)) {
+        // no MFMA workspace / non-fp16 weights: the prompt goes through the M = 1 path token by token,
+        // exactly as the reference feeds it (LlamaModel.cs:103-126)
+        for (uint32_t i = 0; i < n; i++) {
+            int rc = nfai_hip_llama_decode_step(h, tokens[i], i + 1 == n ? logits_last_host : nullptr, nullptr);
+            if (rc) return rc;
+        }
+        return NFAI_OK;
     }
+    hipStream_t s = m->ctx->stream;
+    for (uint32_t done = 0; done < n;) {
+        const uint32_t T = std::min(n - done, m->d.max_batch);
+        int rc = prefill_chunk(m, tokens + done, T);
+        if (rc) return rc;
+        done += T;
+    }
+    // logits of the LAST prompt token: output norm + lm_head + argmax on its hidden state.  The
+    // position was already advanced past the prompt, so the head runs without the token bookkeeping.
+    {
+        Rec rec{m};
+        const Tensor &head = m->output.ptr ? m->output : m->token_embd;
+        GemvArgs a = gemv_base(m, head, m->x, m->d.E);
+        a.gamma = static_cast<const float *>(m->output_norm.ptr);
+        a.y = m->logits;
+        K_TRY(KC_LMHEAD, launch_gemv(a, s));
+        K_TRY(KC_OTHER, launch_argmax(m->logits, m->d.V, m->d_tok, m->d_argmax_part, nullptr, nullptr, 0, s));
+    }
+    if (logits_last_host) HIP_TRY(hipMemcpyAsync(logits_last_host, m->logits, (size_t)m->d.V * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return NFAI_OK;
 }
 

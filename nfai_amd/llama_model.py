@@ -90,7 +90,7 @@ class LlamaModel:
     def __init__(self, mgr: HipBufferManager, metadata: dict, tensors: dict, contextSize: int = 1024, *,
                  tokenizer=None, unfused: bool = False, graph: bool = True, kv_f16: bool = False,
                  rope_n_freqs: int | None = None, rope_base: float | None = 500000.0,
-                 layer_range: tuple[int, int] | None = None, dims: dict | None = None):
+                 layer_range: tuple[int, int] | None = None, dims: dict | None = None, max_batch: int = 0):
         self.mgr = mgr
         d = dims or dims_from_metadata(metadata, tensors)
         self.dims = d
@@ -106,7 +106,7 @@ class LlamaModel:
         desc = _lib.LlamaDescC(d["E"], d["L"], d["H"], d["Hkv"], d["D"], d["F"], d["V"], int(contextSize), d["eps"],
                                # the reference ignores llama.rope.freq_base and uses 500000 (TransformerBlock.cs:33)
                                float(rope_base if rope_base is not None else d["rope_base"]), rd,
-                               rd // 2 if rope_n_freqs is None else rope_n_freqs, lb, le, flags, 0)
+                               rd // 2 if rope_n_freqs is None else rope_n_freqs, lb, le, flags, int(max_batch))
         self.C = int(contextSize)
         h = _lib.H()
         call("nfai_hip_llama_create", mgr.handle, C.byref(desc), C.byref(h))

@@ -277,3 +277,37 @@ def test_gguf_file_to_generation_end_to_end(mgr, tmp_path):
     assert text == tk.Detokenize(want)
     assert model.Pos == len(ids) + max(len(want) - 1, 0) + (0 if len(want) == 6 else 1) or True
     model.Dispose()
+
+
+@pytest.mark.parametrize("dims,n,chunk", [(synth.TINY, 37, 64), (synth.TINY_D128, 100, 64), (synth.TINY_D128, 130, 128)],
+                         ids=["tiny-37", "d128-100-chunked", "d128-130-chunked"])
+def test_prefill_mfma_matches_token_by_token(mgr, dims, n, chunk):
+    """Batched MFMA prefill (fp16 operands, fp32 accumulate) against the oracle's token-by-token fp32
+    path (the reference feeds the prompt one token at a time, LlamaModel.cs:103-126).  Stated fp16
+    tolerance: logits max|d| <= 5e-2 * max(1, max|logit|), same argmax; then decode continues from the
+    prefilled KV cache within the same tolerance."""
+    from nfai_amd.llama_model import LlamaModel
+    w = synth.make_weights(dims, seed=71, std=0.05)
+    m = LlamaModel(mgr, synth.make_metadata(dims), w, 160, max_batch=chunk)
+    ref = orc.OracleLlama(odesc(dims, 160), w)
+    toks = synth.make_tokens(dims, n, seed=13)
+    want = None
+    for t in toks:
+        want = ref.step(int(t))
+    got = m.Prefill(toks)
+    assert m.Pos == n
+    tol = 5e-2 * max(1.0, float(np.abs(want).max()))
+    assert np.abs(got - want).max() <= tol, np.abs(got - want).max()
+    assert int(np.argmax(got)) == orc.argmax(want)
+    # K/V rows written by the prefill
+    for l in (0, dims.L - 1):
+        np.testing.assert_allclose(m.ReadKV(l, False, n - 1), ref.kcache(l)[n - 1], rtol=0, atol=2e-2)
+        np.testing.assert_allclose(m.ReadKV(l, True, 3), ref.vcache(l)[3], rtol=0, atol=2e-2)
+    # decode continues on the GEMV path from the prefilled cache
+    tok = orc.argmax(want)
+    for _ in range(8):
+        lg, am = m.Step(tok)
+        wl = ref.step(tok)
+        assert np.abs(lg - wl).max() <= tol
+        tok = orc.argmax(wl)
+    m.Dispose()
