@@ -163,7 +163,8 @@ int32_t nfai_hip_gemv_qkv_rope(nfai_ctx_t ctx, nfai_buf_t Wq, nfai_buf_t Wk, nfa
 enum nfai_llama_flags {
     NFAI_LLAMA_UNFUSED = 1u << 0,   /* run the 16-op chain 1:1 with the reference (parity mode) */
     NFAI_LLAMA_NO_GRAPH = 1u << 1,  /* fused kernels, eager launches (no hipGraph) */
-    NFAI_LLAMA_KV_F16 = 1u << 2     /* fp16 KV cache (default fp32 = the reference's) */
+    NFAI_LLAMA_KV_F16 = 1u << 2,    /* fp16 KV cache (default fp32 = the reference's) */
+    NFAI_LLAMA_PREFETCH = 1u << 3   /* side-stream prefetch of the next GEMV's first weight bytes (perf hint only) */
 };
 
 typedef struct nfai_llama_desc {

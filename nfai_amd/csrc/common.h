@@ -81,8 +81,8 @@ struct GemvArgs {
     const float *rope_cs = nullptr;  // [rope_dims/2][2] cos,sin for the current position (device)
     uint32_t rope_dims = 0, H = 0, Hkv = 0, D = 0;
     const uint32_t *pos_dev = nullptr;  // current position (device scalar)
-    // optional fused argmax partials (lm_head)
     uint32_t n_cu = 256;
+    bool prefetch_only = false;  // side-stream launch that only touches the first two steps of every wave's weights
 };
 enum GemvMode { GEMV_PLAIN = 0, GEMV_RESIDUAL = 1, GEMV_QKV_ROPE = 2, GEMV_GATEUP = 3 };
 

@@ -16,6 +16,8 @@
 //                wave are always in flight, across row boundaries too
 //  block       = 4..8 waves sharing x in LDS; grid = one or two blocks per CU, sized by the
 //                host so that units divide evenly over all waves (no tail wave)
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace nfai {
@@ -36,6 +38,7 @@ struct GemvParams {
     uint32_t rope_dims, D;
     const uint32_t *pos;
     int kv_f16;
+    uint32_t prefetch_only;  // 1: touch the first two steps of every wave's weights (default cache policy) and exit
 };
 
 #define GLOBAL_AS __attribute__((address_space(1)))
@@ -199,6 +202,29 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
     const uint32_t nsteps = ngroups * cpg;
     const uint32_t kpad = p.KC * 64 * EPL;
 
+    // ---- prefetch-only launch (runs on a side stream while the PREVIOUS kernel of the token is still
+    //      streaming): request exactly the bytes this kernel's waves will ask for first, with the
+    //      default cache policy so they stay in L2 / Infinity Cache across the kernel boundary -------
+    if (p.prefetch_only) {
+        uint32_t acc = 0;
+        for (uint32_t st = 0; st < min(nsteps, 2u); st++) {
+            const uint32_t g = st / cpg, cg = st % cpg;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint32_t u = min(min(u_begin + g * UPW + r / RPU, u_end - 1), p.NU - 1);
+                const uint8_t *row = row_ptr<MODE>(p, u, r % RPU);
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    const uint32_t k = min((cg * U + j) * (64 * EPL) + lane * EPL, p.K - EPL);
+                    const u32x4 v = *reinterpret_cast<const GLOBAL_AS u32x4 *>((const GLOBAL_AS uint8_t *)row + (uint64_t)k * (WT == NFAI_F16 ? 2 : 4));
+                    acc ^= v[0];
+                }
+            }
+        }
+        asm volatile("" ::"v"(acc));  // keep the loads; nothing is stored
+        return;
+    }
+
     // ---- (1) the activation loads go out FIRST: vmcnt retires in order, so the prologue below can
     //      wait for x while every weight load issued after it stays in flight --------------------
     f32x4 xv[XN], gv[NORM ? XN : 1];
@@ -355,12 +381,18 @@ static GemvPlan plan_gemv(uint32_t NU, uint32_t K, int epl, int rpu, uint32_t n_
     uint32_t grid = n_cu;
     if (!exact && NU < n_cu * 4) { grid = (NU + 3) / 4; wpb = 4; }  // tiny problems: fewer blocks
     if (grid == 0) grid = 1;
+    // tuning overrides (bench sweeps only): blocks per CU and waves per block
+    static const int env_bpc = getenv("NFAI_GEMV_BPC") ? atoi(getenv("NFAI_GEMV_BPC")) : 0;
+    static const int env_wpb = getenv("NFAI_GEMV_WPB") ? atoi(getenv("NFAI_GEMV_WPB")) : 0;
+    static const int env_maxld = getenv("NFAI_GEMV_MAXLD") ? atoi(getenv("NFAI_GEMV_MAXLD")) : 16;
+    if (env_wpb >= 1 && env_wpb <= 8 && NU >= n_cu * 8) wpb = (uint32_t)env_wpb;
+    if (env_bpc >= 1 && env_bpc <= 4 && NU >= n_cu * 8) grid = n_cu * (uint32_t)env_bpc;
     const uint32_t upw_total = (NU + grid * wpb - 1) / (grid * wpb);  // units per wave (max)
     // units per step: rows_in_flight * u <= 16 loads per lane per step (x2 for the register double
     // buffer = 128 VGPRs), and divide upw_total if we can
     int upw = 1;
     for (int c = 4; c >= 1; c--) {
-        if (c * rpu * pl.u <= 16 && upw_total % c == 0) { upw = c; break; }
+        if (c * rpu * pl.u <= env_maxld && upw_total % c == 0) { upw = c; break; }
     }
     // the block must hold x in XN float4 per thread (XN = 4 with RMSNorm, 16 without)
     const uint32_t xn = norm ? 4 : 16;
@@ -459,6 +491,7 @@ hipError_t launch_gemv(const GemvArgs &a, hipStream_t s)
     p.D = a.D;
     p.pos = a.pos_dev;
     p.kv_f16 = a.kv_type == NFAI_F16;
+    p.prefetch_only = a.prefetch_only ? 1u : 0u;
     const GemvPlan pl = plan_gemv(p.NU, a.K, epl, rpu, a.n_cu, a.gamma != nullptr);
     if (!pl.ok) return hipErrorInvalidValue;
     p.KC = (a.K + 64 * epl - 1) / (64 * epl);

@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 
 #include <map>
 #include <string>
@@ -71,6 +72,9 @@ struct Model {
     uint32_t pos_host = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    bool prefetch = false, s2_used = false;  // side-stream weight prefetch (NFAI_LLAMA_PREFETCH)
+    hipStream_t s2 = nullptr;
+    std::vector<hipEvent_t> pf_events;
     hipGraph_t stage_graph = nullptr;      // pipeline-stage graph, captured per (hidden_in, hidden_out)
     hipGraphExec_t stage_exec = nullptr;
     const void *stage_in = nullptr;
@@ -182,6 +186,97 @@ struct Rec {
         if (_rc) return _rc;                                                                                    \
     } while (0)
 
+// ---- launch scheduler with a one-op look-ahead ------------------------------------------------------
+// Every short GEMV pays ~3 us of dispatch + first-byte latency + drain during which HBM idles.  With
+// NFAI_LLAMA_PREFETCH, when op i+1 is an fp16 GEMV its "prefetch-only" twin (the same grid touching
+// exactly the bytes each wave requests first, default cache policy) is launched on a side stream as
+// soon as op i-1 has finished, i.e. concurrently with op i: the requests straddle the i -> i+1
+// boundary and op i+1 finds its first two steps in L2 / Infinity Cache.  Pure performance hint: no
+// result depends on it (the side stream writes nothing).
+struct Op {
+    int kind = 2;  // 0 gemv, 1 attention, 2 generic
+    int cls = KC_OTHER;
+    GemvArgs g;
+    AttnArgs a;
+    std::function<hipError_t(hipStream_t)> f;
+};
+
+struct Sched {
+    Model *m;
+    Rec rec;
+    bool have = false;
+    Op pending;
+    size_t ev_i = 0;
+
+    int launch_now(const Op &op)
+    {
+        hipStream_t s = m->ctx->stream;
+        int rc = rec.begin(op.cls);
+        if (rc) return rc;
+        hipError_t e = op.kind == 0 ? launch_gemv(op.g, s) : (op.kind == 1 ? launch_attn_decode(op.a, s) : op.f(s));
+        if (e != hipSuccess)
+            return fail(e == hipErrorInvalidValue ? NFAI_ERR_INVALID : NFAI_ERR_HIP, "launch (class %d) failed: %s", op.cls,
+                        hipGetErrorString(e));
+        return rec.end();
+    }
+    int submit(const Op &op)
+    {
+        if (have) {
+            const bool pf = m->prefetch && !m->profiling && op.kind == 0 && op.g.w_type == NFAI_F16;
+            if (pf) {
+                if (ev_i >= m->pf_events.size()) {
+                    hipEvent_t e;
+                    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                    m->pf_events.push_back(e);
+                }
+                hipEvent_t ev = m->pf_events[ev_i++];
+                HIP_TRY(hipEventRecord(ev, m->ctx->stream));       // everything before `pending`
+                HIP_TRY(hipStreamWaitEvent(m->s2, ev, 0));
+                GemvArgs g = op.g;
+                g.prefetch_only = true;
+                hipError_t e = launch_gemv(g, m->s2);
+                if (e != hipSuccess) return fail(NFAI_ERR_HIP, "prefetch launch failed: %s", hipGetErrorString(e));
+                m->s2_used = true;
+            }
+            int rc = launch_now(pending);
+            if (rc) return rc;
+        }
+        pending = op;
+        have = true;
+        return NFAI_OK;
+    }
+    int flush()
+    {
+        if (have) {
+            int rc = launch_now(pending);
+            if (rc) return rc;
+            have = false;
+        }
+        if (m->s2_used) {  // join the side stream (required to end a capture; harmless otherwise)
+            if (ev_i >= m->pf_events.size()) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                m->pf_events.push_back(e);
+            }
+            hipEvent_t ev = m->pf_events[ev_i++];
+            HIP_TRY(hipEventRecord(ev, m->s2));
+            HIP_TRY(hipStreamWaitEvent(m->ctx->stream, ev, 0));
+            m->s2_used = false;
+        }
+        return NFAI_OK;
+    }
+};
+
+#define S_TRY(expr)            \
+    do {                       \
+        int _rc = (expr);      \
+        if (_rc) return _rc;   \
+    } while (0)
+
+static Op op_gemv(int cls, const GemvArgs &g) { Op o; o.kind = 0; o.cls = cls; o.g = g; return o; }
+static Op op_attn(int cls, const AttnArgs &a) { Op o; o.kind = 1; o.cls = cls; o.a = a; return o; }
+static Op op_fn(int cls, std::function<hipError_t(hipStream_t)> f) { Op o; o.kind = 2; o.cls = cls; o.f = std::move(f); return o; }
+
 GemvArgs gemv_base(Model *m, const Tensor &w, const float *x, uint32_t K)
 {
     GemvArgs a;
@@ -197,10 +292,9 @@ GemvArgs gemv_base(Model *m, const Tensor &w, const float *x, uint32_t K)
 }
 
 // One block, fused path (TransformerBlock.cs:127-184 in five launches + the attention merge).
-int block_fused(Model *m, Layer &L, Rec &rec)
+int block_fused(Model *m, Layer &L, Sched &sch)
 {
     const nfai_llama_desc &d = m->d;
-    hipStream_t s = m->ctx->stream;
     {
         // One launch when q, k, v share an encoding; Q4_K_M files keep attn_v in Q6_K on some blocks:
         // then the segments that differ get their own launch (same kernel family, same epilogue).
@@ -222,7 +316,7 @@ int block_fused(Model *m, Layer &L, Rec &rec)
             a.kv_pos_stride = m->kv_pos_stride; a.kv_head_stride = m->kv_head_stride;
             a.rope_cs = m->d_ropecs; a.rope_dims = d.rope_dims;
             a.H = d.H; a.Hkv = d.Hkv; a.D = d.D;
-            K_TRY(KC_QKV, launch_gemv(a, s));
+            S_TRY(sch.submit(op_gemv(KC_QKV, a)));
             first = last + 1;
         }
     }
@@ -234,24 +328,24 @@ int block_fused(Model *m, Layer &L, Rec &rec)
         a.o = m->att; a.H = d.H; a.Hkv = d.Hkv; a.D = d.D; a.C = d.C;
         a.pos_dev = m->d_pos; a.partials = m->d_attn_part;
         a.n_cu = (uint32_t)m->ctx->prop.multiProcessorCount;
-        K_TRY(KC_ATTN, launch_attn_decode(a, s));
+        S_TRY(sch.submit(op_attn(KC_ATTN, a)));
     }
     {
         GemvArgs a = gemv_base(m, L.wo, m->att, d.H * d.D);
         a.mode = GEMV_RESIDUAL; a.res = m->x; a.y = m->h;
-        K_TRY(KC_WO, launch_gemv(a, s));
+        S_TRY(sch.submit(op_gemv(KC_WO, a)));
     }
     {
         GemvArgs a = gemv_base(m, L.wgate, m->h, d.E);
         a.W[1] = L.wup.ptr; a.seg_rows[1] = (uint32_t)L.wup.rows;
         a.gamma = static_cast<const float *>(L.ffn_norm.ptr);
         a.mode = GEMV_GATEUP; a.y = m->act;
-        K_TRY(KC_GATEUP, launch_gemv(a, s));
+        S_TRY(sch.submit(op_gemv(KC_GATEUP, a)));
     }
     {
         GemvArgs a = gemv_base(m, L.wdown, m->act, d.F);
         a.mode = GEMV_RESIDUAL; a.res = m->h; a.y = m->x;
-        K_TRY(KC_DOWN, launch_gemv(a, s));
+        S_TRY(sch.submit(op_gemv(KC_DOWN, a)));
     }
     return NFAI_OK;
 }
@@ -299,28 +393,41 @@ int enqueue_token(Model *m, bool with_head)
         K_TRY(KC_OTHER, launch_embed_kq(m->token_embd.ptr, m->token_embd.type, m->token_embd.rows, m->d_tok, m->x, d.E, s));
     K_TRY(KC_OTHER, launch_token_begin(m->first_stage && !emb_kq ? m->token_embd.ptr : nullptr, m->token_embd.type, m->d_tok, m->x, d.E,
                                        m->d_freqs, m->d_ropecs, nfreq, m->d_pos, s));
-    for (Layer &L : m->layers) {
-        int rc = m->unfused ? block_unfused(m, L, rec) : block_fused(m, L, rec);
-        if (rc) return rc;
-    }
-    if (m->last_stage && with_head) {
-        const Tensor &head = m->output.ptr ? m->output : m->token_embd;  // tied when output.weight is absent (LlamaModel.cs:64-67)
-        if (m->unfused) {
+    if (m->unfused) {
+        for (Layer &L : m->layers) {
+            int rc = block_unfused(m, L, rec);
+            if (rc) return rc;
+        }
+        if (m->last_stage && with_head) {
+            const Tensor &head = m->output.ptr ? m->output : m->token_embd;  // tied when output.weight is absent (LlamaModel.cs:64-67)
             K_TRY(KC_OTHER, launch_rmsnorm(m->x, static_cast<const float *>(m->output_norm.ptr), m->xn, d.E, d.eps, s));
             GemvArgs a = gemv_base(m, head, m->xn, d.E);
             a.y = m->logits;
             K_TRY(KC_LMHEAD, launch_gemv(a, s));
+            K_TRY(KC_OTHER, launch_argmax(m->logits, d.V, m->d_tok, m->d_argmax_part, m->d_pos, m->d_ring, RING_LEN, s));
         } else {
-            GemvArgs a = gemv_base(m, head, m->x, d.E);
-            a.gamma = static_cast<const float *>(m->output_norm.ptr);
-            a.y = m->logits;
-            K_TRY(KC_LMHEAD, launch_gemv(a, s));
+            K_TRY(KC_OTHER, launch_pos_advance(m->d_pos, s));
         }
-        K_TRY(KC_OTHER, launch_argmax(m->logits, d.V, m->d_tok, m->d_argmax_part, m->d_pos, m->d_ring, RING_LEN, s));
-    } else {
-        K_TRY(KC_OTHER, launch_pos_advance(m->d_pos, s));
+        return NFAI_OK;
     }
-    return NFAI_OK;
+    Sched sch{m, rec};
+    for (Layer &L : m->layers) {
+        int rc = block_fused(m, L, sch);
+        if (rc) return rc;
+    }
+    if (m->last_stage && with_head) {
+        const Tensor &head = m->output.ptr ? m->output : m->token_embd;
+        GemvArgs a = gemv_base(m, head, m->x, d.E);
+        a.gamma = static_cast<const float *>(m->output_norm.ptr);
+        a.y = m->logits;
+        S_TRY(sch.submit(op_gemv(KC_LMHEAD, a)));
+        S_TRY(sch.submit(op_fn(KC_OTHER, [m](hipStream_t st) {
+            return launch_argmax(m->logits, m->d.V, m->d_tok, m->d_argmax_part, m->d_pos, m->d_ring, RING_LEN, st);
+        })));
+    } else {
+        S_TRY(sch.submit(op_fn(KC_OTHER, [m](hipStream_t st) { return launch_pos_advance(m->d_pos, st); })));
+    }
+    return sch.flush();
 }
 
 int ensure_graph(Model *m)
@@ -397,6 +504,11 @@ NFAI_API int32_t nfai_hip_llama_create(nfai_ctx_t ch, const nfai_llama_desc *des
     m->unfused = (d.flags & NFAI_LLAMA_UNFUSED) != 0;
     m->use_graph = (d.flags & NFAI_LLAMA_NO_GRAPH) == 0;
     m->kv_f16 = (d.flags & NFAI_LLAMA_KV_F16) != 0;
+    {
+        const char *env = getenv("NFAI_PREFETCH");
+        m->prefetch = env ? (env[0] == '1') : ((d.flags & NFAI_LLAMA_PREFETCH) != 0);
+        if (m->prefetch) HIP_TRY(hipStreamCreateWithFlags(&m->s2, hipStreamNonBlocking));
+    }
     if (m->unfused && m->kv_f16) { delete m; return fail(NFAI_ERR_INVALID, "llama_create: the 1:1 chain keeps the reference's fp32 KV cache"); }
     m->layers.resize(d.layer_end - d.layer_begin);
     m->kv_esz = m->kv_f16 ? 2 : 4;
@@ -477,6 +589,8 @@ NFAI_API int32_t nfai_hip_llama_destroy(nfai_model_t h)
     hipStreamSynchronize(m->ctx->stream);
     if (m->graph_exec) hipGraphExecDestroy(m->graph_exec);
     if (m->graph) hipGraphDestroy(m->graph);
+    for (hipEvent_t e : m->pf_events) hipEventDestroy(e);
+    if (m->s2) hipStreamDestroy(m->s2);
     if (m->stage_exec) hipGraphExecDestroy(m->stage_exec);
     if (m->stage_graph) hipGraphDestroy(m->stage_graph);
     for (hipEvent_t e : m->ev) hipEventDestroy(e);
