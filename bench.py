@@ -229,6 +229,15 @@ def run_single(args):
             a = prof.setdefault(k, [0.0, 0])
             a[0] += ms
             a[1] += n
+    # HBM traffic of the dominant kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
+    # passes, gfx950 correction applied): collected offline on the same build, committed under profiles/
+    traffic = None
+    try:
+        if args.model == "llama-3.2-3b" and args.quant == "f16":
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))
+            traffic = pmc["kernels"]["nfai::k_gemv<1, 3, 2, 3, false, true>"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        traffic = None
     gu_ms = prof["gateup"][0] / max(1, prof["gateup"][1]) if prof else float("nan")
     achieved = dom_bytes / (gu_ms * 1e-3) / 1e9
     per_kernel_us = {k: round(1e3 * v[0] / v[1], 3) for k, v in prof.items() if v[1]}
@@ -242,7 +251,7 @@ def run_single(args):
                    "positions": [pos0, pos0 + args.steps - 1], "kv_capacity": C, "parallelism": "single",
                    "graph": not args.no_graph},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "kernel": ("k_gemv<F16,GATEUP>" if args.quant == "f16" else "k_gemv_kq<Q4_K,GATEUP>") + " (RMSNorm + Wgate/Wup GEMV + SiLU*up)",
                      "bytes_per_launch": dom_bytes, "us_per_launch": gu_ms * 1e3},
         "token_hbm_gbps": b_tok / (ms_per_step * 1e-3) / 1e9,

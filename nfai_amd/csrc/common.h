@@ -99,6 +99,8 @@ struct GemmArgs {  // C[M][N] (+R) = alpha * A[M][K] * B[N][K]^T, fp16 operands,
     const void *A = nullptr;   // fp16, or fp32 when a_f32 (converted while staging)
     bool a_f32 = false;
     const void *B = nullptr;   // fp16 [N][ldb]
+    const void *B1 = nullptr, *B2 = nullptr;  // optional 2nd / 3rd row segment (rows n0.., n0+n1..); all segments ldb wide
+    uint32_t n0 = 0, n1 = 0;
     float *C = nullptr;
     const float *R = nullptr;  // optional residual, same layout as C
     uint32_t M = 0, N = 0, K = 0, lda = 0, ldb = 0, ldc = 0;
@@ -107,15 +109,16 @@ struct GemmArgs {  // C[M][N] (+R) = alpha * A[M][K] * B[N][K]^T, fp16 operands,
     float alpha = 1.0f;
 };
 hipError_t launch_gemm_f16(const GemmArgs &a, hipStream_t s);
+hipError_t launch_f32_to_f16(const float *x, void *y_f16, uint64_t n, hipStream_t s);
 hipError_t launch_rmsnorm_rows(const float *x, const float *g, void *y_f16, uint32_t T, uint32_t E, float eps, hipStream_t s);
 hipError_t launch_rope_store_rows(const float *q, const float *k, const float *v, void *qh_f16, void *kc, void *vc, int kv_f16,
                                   uint64_t pos_stride, uint64_t head_stride, const float *freqs, uint32_t rope_dims, uint32_t H,
-                                  uint32_t Hkv, uint32_t D, uint32_t pos0, uint32_t T, hipStream_t s);
+                                  uint32_t Hkv, uint32_t D, uint32_t pos0, uint32_t T, uint32_t ld, hipStream_t s);
 hipError_t launch_kv_to_f16(const void *kc, const void *vc, int kv_f16, uint64_t pos_stride, uint64_t head_stride, void *kh, void *vt,
                             uint32_t Hkv, uint32_t D, uint32_t S, uint32_t Spad, hipStream_t s);
 hipError_t launch_softmax_causal_rows(const float *sc, void *p_f16, uint32_t H, uint32_t T, uint32_t Spad, uint32_t pos0, float scale,
                                       hipStream_t s);
-hipError_t launch_silu_mul_rows(const float *gate, const float *up, void *act_f16, uint64_t n, hipStream_t s);
+hipError_t launch_silu_mul_rows(const float *gate, const float *up, void *act_f16, uint32_t T, uint32_t F, uint32_t ld, hipStream_t s);
 hipError_t launch_embed_rows(const void *table, int type, const uint32_t *toks, float *x, uint32_t T, uint32_t E, hipStream_t s);
 
 struct AttnArgs {

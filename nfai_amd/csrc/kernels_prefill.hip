@@ -10,11 +10,11 @@
 //
 // GEMM  C[M][N] (+R) = A[M][K] * B[N][K]^T      (B = GGUF weight matrix as stored: K contiguous)
 //   bound: MFMA for M = 512 (2*M*N*K flop over (M + N)*K*2 B of operands), HBM for small M.
-//   tile 128 x 64 x 64, 256 threads = 4 waves stacked on M (32 rows x 64 cols each = 2 x 4 MFMA
-//   tiles, 16 MFMAs per wave per K tile); operands staged global -> VGPR -> LDS (two buffers, the
-//   next tile's global loads are in flight during the MFMAs, one barrier per K tile); LDS rows are
-//   128 B with the 16-byte chunk index XOR (row & 7) so the ds_read_b128 fragment reads of 16 rows
-//   at one k-chunk spread over 8 bank groups; A may be fp32 in memory (converted while staging).
+//   tile 128 x 64 x 128 (x 64 when K % 128 != 0), 256 threads = 4 waves stacked on M (32 rows x 64
+//   cols each = 2 x 4 MFMA tiles, 32 MFMAs per wave per K tile); operands staged global -> VGPR ->
+//   LDS: two LDS buffers and a ring of three register sets, so two K tiles of global loads are in
+//   flight during the MFMAs (one barrier per K tile); LDS chunk index XOR row => conflict-free
+//   ds_read_b128 fragment reads; up to three weight segments per launch (q|k|v, gate|up).
 //   blockIdx -> (m tile, n tile) is XCD-aware: the m tiles that share a weight tile get ids that are
 //   equal mod 8 (same XCD, adjacent dispatch slots), so a weight tile is read from HBM once and from
 //   that XCD's L2 by the other m tiles.
@@ -27,11 +27,12 @@ namespace nfai {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int GBM = 128, GBN = 64, GBK = 64, GTHREADS = 256;
+constexpr int GBM = 128, GBN = 64, GTHREADS = 256;
 
 struct GemmParams {
-    const void *A;          // [M][lda] fp16 or fp32
-    const _Float16 *B;      // [N][ldb] fp16
+    const _Float16 *A;      // [M][lda] fp16
+    const _Float16 *B[3];   // up to three row segments of [rows][ldb] fp16 (q | k | v, gate | up) — one launch
+    uint32_t seg_end[3];    // cumulative row ends of the segments (multiples of 64)
     float *C;               // [M][ldc] fp32
     const float *R;         // optional residual [M][ldc]
     uint32_t M, N, K, lda, ldb, ldc;
@@ -40,14 +41,26 @@ struct GemmParams {
     float alpha;
 };
 
-__device__ __forceinline__ uint32_t lds_off(uint32_t row, uint32_t chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+// LDS tile rows are BK halves = CH chunks of 16 B; the chunk index is XORed with the row so that the
+// 16 rows a ds_read_b128 fragment read touches at one k-chunk land in 16 different bank groups
+template <int CH> __device__ __forceinline__ uint32_t lds_off(uint32_t row, uint32_t chunk)
+{
+    return row * (CH * 16) + ((chunk ^ (row & (CH - 1))) << 4);
+}
 
-template <bool A_F32>
+// BK = 64 or 128.  Global -> VGPR -> LDS with a ring of three register sets: while tile kt is
+// multiplied out of LDS, tile kt+1 sits in registers and tile kt+2 is in flight (the projections run
+// at one block per CU, so nothing else hides the ~2000-cycle global latency).
+template <int BK>
 __global__ __launch_bounds__(GTHREADS) void k_gemm_f16(const GemmParams p)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * (GBM + GBN) * 128];
-    auto ldsA = [&](int buf) -> uint8_t * { return lds + buf * (GBM + GBN) * 128; };
-    auto ldsB = [&](int buf) -> uint8_t * { return lds + buf * (GBM + GBN) * 128 + GBM * 128; };
+    constexpr int CH = BK / 8;                      // 16-byte chunks per tile row
+    constexpr int AN = GBM * CH / GTHREADS;         // A chunks per thread per tile
+    constexpr int BN_ = GBN * CH / GTHREADS;        // B chunks per thread per tile
+    constexpr int TILE_BYTES = (GBM + GBN) * BK * 2;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    auto ldsA = [&](int buf) -> uint8_t * { return lds + buf * TILE_BYTES; };
+    auto ldsB = [&](int buf) -> uint8_t * { return lds + buf * TILE_BYTES + GBM * BK * 2; };
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t tiles_m = (p.M + GBM - 1) / GBM, tiles_n = p.N / GBN;
@@ -64,54 +77,39 @@ __global__ __launch_bounds__(GTHREADS) void k_gemm_f16(const GemmParams p)
         }
     }
     const uint32_t m0 = mt_i * GBM, n0 = nt_i * GBN, batch = blockIdx.y;
-    const uint8_t *Ab = static_cast<const uint8_t *>(p.A) + (uint64_t)batch * p.a_bs * (A_F32 ? 4 : 2);
-    const _Float16 *Bb = p.B + (uint64_t)(batch / p.b_div) * p.b_bs;
+    const GLOBAL_AS uint8_t *Ab = (const GLOBAL_AS uint8_t *)(p.A + (uint64_t)batch * p.a_bs);
+    // weight segment of this n tile
+    const uint32_t seg = n0 < p.seg_end[0] ? 0u : (n0 < p.seg_end[1] ? 1u : 2u);
+    const uint32_t nrow0 = n0 - (seg == 0 ? 0u : p.seg_end[seg - 1]);
+    const GLOBAL_AS uint8_t *Bb = (const GLOBAL_AS uint8_t *)(p.B[seg] + (uint64_t)(batch / p.b_div) * p.b_bs);
     float *Cb = p.C + (uint64_t)batch * p.c_bs;
     const float *Rb = p.R ? p.R + (uint64_t)batch * p.c_bs : nullptr;
 
-    // staging registers: A 128x64 halves = 1024 16-byte chunks (4 per thread) — or, from fp32, 2048
-    // 16-byte loads of 4 floats (8 per thread); B 64x64 halves = 512 chunks (2 per thread)
-    constexpr int AN = A_F32 ? 8 : 4;
-    u32x4 ra[AN], rb[2];
-    auto load_tile = [&](uint32_t kt) {
-        const uint32_t k0 = kt * GBK;
+    u32x4 ra[3][AN], rb[3][BN_];
+    auto load_tile = [&](u32x4 (&a)[AN], u32x4 (&b)[BN_], uint32_t kt) {
+        const uint32_t k0 = kt * BK;
 #pragma unroll
         for (int i = 0; i < AN; i++) {
-            const uint32_t c = tid + i * GTHREADS;
-            if constexpr (A_F32) {
-                const uint32_t row = c >> 4, q = c & 15;  // 16 float4 per row
-                const uint32_t gr = min(m0 + row, p.M - 1);
-                ra[i] = *reinterpret_cast<const GLOBAL_AS u32x4 *>((const GLOBAL_AS uint8_t *)Ab + ((uint64_t)gr * p.lda + k0 + q * 4) * 4);
-            } else {
-                const uint32_t row = c >> 3, q = c & 7;   // 8 chunks of 8 halves per row
-                const uint32_t gr = min(m0 + row, p.M - 1);
-                ra[i] = *reinterpret_cast<const GLOBAL_AS u32x4 *>((const GLOBAL_AS uint8_t *)Ab + ((uint64_t)gr * p.lda + k0 + q * 8) * 2);
-            }
+            const uint32_t c = tid + i * GTHREADS, row = c / CH, q = c % CH;
+            const uint32_t gr = min(m0 + row, p.M - 1);
+            a[i] = *reinterpret_cast<const GLOBAL_AS u32x4 *>(Ab + ((uint64_t)gr * p.lda + k0 + q * 8) * 2);
         }
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const uint32_t c = tid + i * GTHREADS, row = c >> 3, q = c & 7;
-            rb[i] = *reinterpret_cast<const GLOBAL_AS u32x4 *>((const GLOBAL_AS uint8_t *)Bb + ((uint64_t)(n0 + row) * p.ldb + k0 + q * 8) * 2);
+        for (int i = 0; i < BN_; i++) {
+            const uint32_t c = tid + i * GTHREADS, row = c / CH, q = c % CH;
+            b[i] = *reinterpret_cast<const GLOBAL_AS u32x4 *>(Bb + ((uint64_t)(nrow0 + row) * p.ldb + k0 + q * 8) * 2);
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](const u32x4 (&a)[AN], const u32x4 (&b)[BN_], int buf) {
 #pragma unroll
         for (int i = 0; i < AN; i++) {
-            const uint32_t c = tid + i * GTHREADS;
-            if constexpr (A_F32) {
-                const uint32_t row = c >> 4, q = c & 15;
-                const f32x4 v = __builtin_bit_cast(f32x4, ra[i]);
-                const f16x4 h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                *reinterpret_cast<f16x4 *>(ldsA(buf) + lds_off(row, q >> 1) + (q & 1) * 8) = h;
-            } else {
-                const uint32_t row = c >> 3, q = c & 7;
-                *reinterpret_cast<u32x4 *>(ldsA(buf) + lds_off(row, q)) = ra[i];
-            }
+            const uint32_t c = tid + i * GTHREADS, row = c / CH, q = c % CH;
+            *reinterpret_cast<u32x4 *>(ldsA(buf) + lds_off<CH>(row, q)) = a[i];
         }
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const uint32_t c = tid + i * GTHREADS, row = c >> 3, q = c & 7;
-            *reinterpret_cast<u32x4 *>(ldsB(buf) + lds_off(row, q)) = rb[i];
+        for (int i = 0; i < BN_; i++) {
+            const uint32_t c = tid + i * GTHREADS, row = c / CH, q = c % CH;
+            *reinterpret_cast<u32x4 *>(ldsB(buf) + lds_off<CH>(row, q)) = b[i];
         }
     };
 
@@ -121,29 +119,42 @@ __global__ __launch_bounds__(GTHREADS) void k_gemm_f16(const GemmParams p)
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const uint32_t KT = p.K / GBK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (uint32_t kt = 0; kt < KT; kt++) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) load_tile(kt + 1);
+    auto compute = [&](int cur) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
+        for (int ks = 0; ks < BK / 32; ks++) {
             const uint32_t chunk = ks * 4 + (lane >> 4);
             f16x8 af[2], bf[4];
 #pragma unroll
-            for (int i = 0; i < 2; i++) af[i] = *reinterpret_cast<const f16x8 *>(ldsA(cur) + lds_off(wave * 32 + i * 16 + (lane & 15), chunk));
+            for (int i = 0; i < 2; i++) af[i] = *reinterpret_cast<const f16x8 *>(ldsA(cur) + lds_off<CH>(wave * 32 + i * 16 + (lane & 15), chunk));
 #pragma unroll
-            for (int j = 0; j < 4; j++) bf[j] = *reinterpret_cast<const f16x8 *>(ldsB(cur) + lds_off(j * 16 + (lane & 15), chunk));
+            for (int j = 0; j < 4; j++) bf[j] = *reinterpret_cast<const f16x8 *>(ldsB(cur) + lds_off<CH>(j * 16 + (lane & 15), chunk));
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < KT) store_tile(cur ^ 1);
-        __syncthreads();
+    };
+
+    const uint32_t KT = p.K / BK;
+    load_tile(ra[0], rb[0], 0);
+    if (KT > 1) load_tile(ra[1], rb[1], 1);
+    store_tile(ra[0], rb[0], 0);
+    __syncthreads();
+    // iteration kt: [request tile kt+2 into the free register set] [MFMAs on tile kt] [tile kt+1: regs -> LDS] [barrier];
+    // unrolled by three so that every register-set index is a compile-time constant (no scratch)
+#define GEMM_ITER(KT_, S_NEXT2, S_NEXT1)                                         \
+    if ((KT_) < KT) {                                                            \
+        if ((KT_) + 2 < KT) load_tile(ra[S_NEXT2], rb[S_NEXT2], (KT_) + 2);      \
+        compute((KT_)&1);                                                        \
+        if ((KT_) + 1 < KT) store_tile(ra[S_NEXT1], rb[S_NEXT1], ((KT_) + 1) & 1); \
+        __syncthreads();                                                         \
     }
+    for (uint32_t kt = 0; kt < KT; kt += 3) {
+        GEMM_ITER(kt, 2, 1)
+        GEMM_ITER(kt + 1, 0, 2)
+        GEMM_ITER(kt + 2, 1, 0)
+    }
+#undef GEMM_ITER
 
     // C/D layout of mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
@@ -164,16 +175,47 @@ __global__ __launch_bounds__(GTHREADS) void k_gemm_f16(const GemmParams p)
 hipError_t launch_gemm_f16(const GemmArgs &a, hipStream_t s)
 {
     if (a.M == 0 || a.N == 0) return hipSuccess;
-    if (a.N % GBN != 0 || a.K % GBK != 0 || a.K == 0) return hipErrorInvalidValue;
-    if (a.lda % 8 != 0 || a.ldb % 8 != 0) return hipErrorInvalidValue;
+    if (a.N % GBN != 0 || a.K % 64 != 0 || a.K == 0) return hipErrorInvalidValue;
+    if (a.lda % 8 != 0 || a.ldb % 8 != 0 || a.a_f32) return hipErrorInvalidValue;
     GemmParams p{};
-    p.A = a.A; p.B = static_cast<const _Float16 *>(a.B); p.C = a.C; p.R = a.R;
+    p.A = static_cast<const _Float16 *>(a.A);
+    p.B[0] = static_cast<const _Float16 *>(a.B);
+    p.B[1] = static_cast<const _Float16 *>(a.B1 ? a.B1 : a.B);
+    p.B[2] = static_cast<const _Float16 *>(a.B2 ? a.B2 : a.B);
+    p.seg_end[0] = a.B1 ? a.n0 : a.N;
+    p.seg_end[1] = a.B2 ? a.n0 + a.n1 : a.N;
+    p.seg_end[2] = a.N;
+    if ((p.seg_end[0] | p.seg_end[1]) % GBN) return hipErrorInvalidValue;
+    p.C = a.C; p.R = a.R;
     p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldb = a.ldb; p.ldc = a.ldc;
     p.a_bs = a.a_bs; p.b_bs = a.b_bs; p.c_bs = a.c_bs; p.b_div = a.b_div ? a.b_div : 1; p.alpha = a.alpha;
     const uint32_t tiles = ((a.M + GBM - 1) / GBM) * (a.N / GBN);
     const dim3 grid(tiles, a.batch ? a.batch : 1);
-    if (a.a_f32) hipLaunchKernelGGL((k_gemm_f16<true>), grid, dim3(GTHREADS), 0, s, p);
-    else hipLaunchKernelGGL((k_gemm_f16<false>), grid, dim3(GTHREADS), 0, s, p);
+    if (a.K % 128 == 0) {
+        constexpr int LDS = 2 * (GBM + GBN) * 128 * 2;  // 96 KiB: above the 64 KiB default limit for dynamic LDS
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<128>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((k_gemm_f16<128>), grid, dim3(GTHREADS), LDS, s, p);
+    } else {
+        hipLaunchKernelGGL((k_gemm_f16<64>), grid, dim3(GTHREADS), 2 * (GBM + GBN) * 64 * 2, s, p);
+    }
+    return hipGetLastError();
+}
+
+// fp32 rows -> fp16 (the attention output on its way into the Wo GEMM)
+__global__ void k_f32_to_f16(const float *x, _Float16 *y, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = (_Float16)x[i];
+}
+
+hipError_t launch_f32_to_f16(const float *x, void *y_f16, uint64_t n, hipStream_t s)
+{
+    k_f32_to_f16<<<(uint32_t)((n + 255) / 256), 256, 0, s>>>(x, static_cast<_Float16 *>(y_f16), n);
     return hipGetLastError();
 }
 
@@ -200,7 +242,7 @@ hipError_t launch_rmsnorm_rows(const float *x, const float *g, void *y_f16, uint
 // RoPE on T rows of q (-> fp16) and k (-> KV cache rows pos0+t), v -> cache rows.  One thread per pair.
 __global__ void k_rope_store_rows(const float *q, const float *k, const float *v, _Float16 *qh, void *kc, void *vc, int kv_f16,
                                   uint64_t pos_stride, uint64_t head_stride, const float *freqs, uint32_t rope_dims, uint32_t H,
-                                  uint32_t Hkv, uint32_t D, uint32_t pos0)
+                                  uint32_t Hkv, uint32_t D, uint32_t pos0, uint32_t ld)
 {
     const uint32_t t = blockIdx.y, half = D / 2;
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -210,7 +252,7 @@ __global__ void k_rope_store_rows(const float *q, const float *k, const float *v
     const uint32_t which = idx < nq ? 0u : (idx < nq + nk ? 1u : 2u);
     const uint32_t li = which == 0 ? idx : (which == 1 ? idx - nq : idx - nq - nk);
     const uint32_t h = li / half, pair = (li % half) * 2;
-    const float *src = which == 0 ? q + (uint64_t)t * H * D : (which == 1 ? k + (uint64_t)t * Hkv * D : v + (uint64_t)t * Hkv * D);
+    const float *src = (which == 0 ? q : (which == 1 ? k : v)) + (uint64_t)t * ld;  // q | k | v may be column blocks of one [T][ld] buffer
     const float a = src[h * D + pair], b = src[h * D + pair + 1];
     float o0 = a, o1 = b;
     if (which < 2 && pair < rope_dims) {
@@ -237,11 +279,11 @@ __global__ void k_rope_store_rows(const float *q, const float *k, const float *v
 
 hipError_t launch_rope_store_rows(const float *q, const float *k, const float *v, void *qh, void *kc, void *vc, int kv_f16,
                                   uint64_t pos_stride, uint64_t head_stride, const float *freqs, uint32_t rope_dims, uint32_t H,
-                                  uint32_t Hkv, uint32_t D, uint32_t pos0, uint32_t T, hipStream_t s)
+                                  uint32_t Hkv, uint32_t D, uint32_t pos0, uint32_t T, uint32_t ld, hipStream_t s)
 {
     const uint32_t n = (H + 2 * Hkv) * D / 2;
     k_rope_store_rows<<<dim3((n + 255) / 256, T), 256, 0, s>>>(q, k, v, static_cast<_Float16 *>(qh), kc, vc, kv_f16, pos_stride,
-                                                               head_stride, freqs, rope_dims, H, Hkv, D, pos0);
+                                                               head_stride, freqs, rope_dims, H, Hkv, D, pos0, ld);
     return hipGetLastError();
 }
 
@@ -311,15 +353,18 @@ hipError_t launch_softmax_causal_rows(const float *sc, void *p_f16, uint32_t H, 
 }
 
 // act = up * silu(gate) over T*F elements, fp16 out (SiLUShader + ElementWiseMultiplicationShader)
-__global__ void k_silu_mul_rows(const float *gate, const float *up, _Float16 *act, uint64_t n)
+__global__ void k_silu_mul_rows(const float *gate, const float *up, _Float16 *act, uint64_t n, uint32_t F, uint32_t ld)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) act[i] = (_Float16)(up[i] * silu_ref(gate[i]));
+    if (i >= n) return;
+    const uint64_t o = (i / F) * ld + (i % F);  // gate | up may be column blocks of one [T][ld] buffer
+    act[i] = (_Float16)(up[o] * silu_ref(gate[o]));
 }
 
-hipError_t launch_silu_mul_rows(const float *gate, const float *up, void *act_f16, uint64_t n, hipStream_t s)
+hipError_t launch_silu_mul_rows(const float *gate, const float *up, void *act_f16, uint32_t T, uint32_t F, uint32_t ld, hipStream_t s)
 {
-    k_silu_mul_rows<<<(uint32_t)((n + 255) / 256), 256, 0, s>>>(gate, up, static_cast<_Float16 *>(act_f16), n);
+    const uint64_t n = (uint64_t)T * F;
+    k_silu_mul_rows<<<(uint32_t)((n + 255) / 256), 256, 0, s>>>(gate, up, static_cast<_Float16 *>(act_f16), n, F, ld);
     return hipGetLastError();
 }
 

@@ -555,12 +555,9 @@ NFAI_API int32_t nfai_hip_llama_create(nfai_ctx_t ch, const nfai_llama_desc *des
         DALLOC(w.toks, T * 4);
         DALLOC(w.X, T * d.E * 4);
         DALLOC(w.H1, T * d.E * 4);
-        DALLOC(w.Q, T * HD * 4);
-        DALLOC(w.K, T * KD * 4);
-        DALLOC(w.V, T * KD * 4);
+        DALLOC(w.Q, T * (HD + 2 * KD) * 4);  // q | k | v columns of one GEMM output
         DALLOC(w.ATT, T * HD * 4);
-        DALLOC(w.G, T * d.F * 4);
-        DALLOC(w.U, T * d.F * 4);
+        DALLOC(w.G, T * d.F * 2 * 4);        // gate | up columns of one GEMM output
         DALLOC(w.SC, (size_t)d.H * T * w.Spad * 4);
         DALLOC(w.XN, T * std::max<size_t>(d.E, HD) * 2);
         DALLOC(w.QH, T * HD * 2);
@@ -782,21 +779,23 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
             return fail(_e == hipErrorInvalidValue ? NFAI_ERR_INVALID : NFAI_ERR_HIP, "prefill: %s failed: %s", #expr, \
                         hipGetErrorString(_e));                                                                   \
     } while (0)
-    auto gemm = [&](const void *A, bool a_f32, uint32_t lda, const Tensor &W, float *C, const float *R, uint32_t N, uint32_t K) {
+    auto gemm = [&](const void *A, uint32_t lda, const Tensor &W, const Tensor *W1, const Tensor *W2, float *C, const float *R, uint32_t N,
+                    uint32_t K) {
         GemmArgs g;
-        g.A = A; g.a_f32 = a_f32; g.lda = lda; g.B = W.ptr; g.ldb = K; g.C = C; g.R = R; g.ldc = N;
+        g.A = A; g.lda = lda; g.B = W.ptr; g.ldb = K; g.C = C; g.R = R; g.ldc = N;
+        if (W1) { g.B1 = W1->ptr; g.n0 = (uint32_t)W.rows; }
+        if (W2) { g.B2 = W2->ptr; g.n1 = (uint32_t)W1->rows; }
         g.M = T; g.N = N; g.K = K;
         return launch_gemm_f16(g, s);
     };
+    const uint32_t QKV = HD + 2 * KD;
     HIP_TRY(hipMemcpyAsync(w.toks, tokens, (size_t)T * 4, hipMemcpyHostToDevice, s));
     P_TRY(launch_embed_rows(m->token_embd.ptr, m->token_embd.type, w.toks, w.X, T, d.E, s));
     for (Layer &L : m->layers) {
         P_TRY(launch_rmsnorm_rows(w.X, static_cast<const float *>(L.attn_norm.ptr), w.XN, T, d.E, d.eps, s));
-        P_TRY(gemm(w.XN, false, d.E, L.wq, w.Q, nullptr, HD, d.E));
-        P_TRY(gemm(w.XN, false, d.E, L.wk, w.K, nullptr, KD, d.E));
-        P_TRY(gemm(w.XN, false, d.E, L.wv, w.V, nullptr, KD, d.E));
-        P_TRY(launch_rope_store_rows(w.Q, w.K, w.V, w.QH, L.kcache, L.vcache, kvf16, m->kv_pos_stride, m->kv_head_stride, m->d_freqs,
-                                     d.rope_dims, d.H, d.Hkv, d.D, pos0, T, s));
+        P_TRY(gemm(w.XN, d.E, L.wq, &L.wk, &L.wv, w.Q, nullptr, QKV, d.E));              // q | k | v in one launch
+        P_TRY(launch_rope_store_rows(w.Q, w.Q + HD, w.Q + HD + KD, w.QH, L.kcache, L.vcache, kvf16, m->kv_pos_stride, m->kv_head_stride,
+                                     m->d_freqs, d.rope_dims, d.H, d.Hkv, d.D, pos0, T, QKV, s));
         P_TRY(launch_kv_to_f16(L.kcache, L.vcache, kvf16, m->kv_pos_stride, m->kv_head_stride, w.KH, w.VT, d.Hkv, d.D, S, Spad, s));
         {   // scores[h][t][s] = q_h[t] . k_kvh[s]   (scaling and the causal limit are applied by the softmax)
             GemmArgs g;
@@ -815,12 +814,12 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
             g.M = T; g.N = d.D; g.K = Spad; g.batch = d.H;
             P_TRY(launch_gemm_f16(g, s));
         }
-        P_TRY(gemm(w.ATT, true, HD, L.wo, w.H1, w.X, d.E, HD));                       // + residual (TransformerBlock.cs:153-158)
+        P_TRY(launch_f32_to_f16(w.ATT, w.XN, (uint64_t)T * HD, s));
+        P_TRY(gemm(w.XN, HD, L.wo, nullptr, nullptr, w.H1, w.X, d.E, HD));                 // + residual (TransformerBlock.cs:153-158)
         P_TRY(launch_rmsnorm_rows(w.H1, static_cast<const float *>(L.ffn_norm.ptr), w.XN, T, d.E, d.eps, s));
-        P_TRY(gemm(w.XN, false, d.E, L.wgate, w.G, nullptr, d.F, d.E));
-        P_TRY(gemm(w.XN, false, d.E, L.wup, w.U, nullptr, d.F, d.E));
-        P_TRY(launch_silu_mul_rows(w.G, w.U, w.ACT, (uint64_t)T * d.F, s));
-        P_TRY(gemm(w.ACT, false, d.F, L.wdown, w.X, w.H1, d.E, d.F));                  // + residual (:176-181)
+        P_TRY(gemm(w.XN, d.E, L.wgate, &L.wup, nullptr, w.G, nullptr, 2 * d.F, d.E));      // gate | up in one launch
+        P_TRY(launch_silu_mul_rows(w.G, w.G + d.F, w.ACT, T, d.F, 2 * d.F, s));
+        P_TRY(gemm(w.ACT, d.F, L.wdown, nullptr, nullptr, w.X, w.H1, d.E, d.F));           // + residual (:176-181)
     }
 #undef P_TRY
     // the last token's hidden state continues on the M = 1 path (output norm + lm_head + argmax)
