@@ -20,6 +20,8 @@
 //    is last: the merge order over slices is fixed (0..nsplit-1), so runs are bit-reproducible.
 // The number of ACTIVE slices depends on the sequence length, which is read from device memory so
 // a captured hipGraph can be replayed for every position; inactive blocks exit at once.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace nfai {
@@ -38,12 +40,13 @@ struct AttnParams {
     uint32_t *tickets;   // [Hkv], zero between launches
     uint32_t H, Hkv, D;
     const uint32_t *pos;
+    uint32_t min_chunk, max_split;  // slicing policy (defaults ATTN_MIN_CHUNK / ATTN_NSPLIT_MAX; env-tunable for sweeps)
 };
 
-__device__ __forceinline__ void attn_split(uint32_t S, uint32_t &nsplit, uint32_t &chunk)
+__device__ __forceinline__ void attn_split(uint32_t S, uint32_t min_chunk, uint32_t max_split, uint32_t &nsplit, uint32_t &chunk)
 {
-    nsplit = (S + ATTN_MIN_CHUNK - 1) / ATTN_MIN_CHUNK;
-    if (nsplit > ATTN_NSPLIT_MAX) nsplit = ATTN_NSPLIT_MAX;
+    nsplit = (S + min_chunk - 1) / min_chunk;
+    if (nsplit > max_split) nsplit = max_split;
     chunk = (S + nsplit - 1) / nsplit;
     nsplit = (S + chunk - 1) / chunk;
 }
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const uint32_t S = p.pos[0] + 1;
     uint32_t nsplit, chunk;
-    attn_split(S, nsplit, chunk);
+    attn_split(S, p.min_chunk, p.max_split, nsplit, chunk);
     const uint32_t kvh = blockIdx.x, split = blockIdx.y;
     if (split >= nsplit) return;
     const uint32_t t0 = split * chunk, t1 = min(t0 + chunk, S), n = t1 - t0;
@@ -288,17 +291,21 @@ hipError_t launch_attn_decode(const AttnArgs &a, hipStream_t s)
     p.tickets = reinterpret_cast<uint32_t *>(a.partials);
     p.partials = a.partials + 64;
     p.H = a.H; p.Hkv = a.Hkv; p.D = a.D; p.pos = a.pos_dev;
+    static const int env_mc = getenv("NFAI_ATTN_MIN_CHUNK") ? atoi(getenv("NFAI_ATTN_MIN_CHUNK")) : 0;
+    static const int env_ms = getenv("NFAI_ATTN_MAX_SPLIT") ? atoi(getenv("NFAI_ATTN_MAX_SPLIT")) : 0;
+    p.min_chunk = env_mc >= 4 ? (uint32_t)env_mc : ATTN_MIN_CHUNK;
+    p.max_split = (env_ms >= 1 && env_ms <= (int)ATTN_NSPLIT_MAX) ? (uint32_t)env_ms : ATTN_NSPLIT_MAX;
     // LDS: scalars + scores of the largest slice the capacity C can produce (also holds the merge
     // weights: G*NSPLIT_MAX*2 floats) + the V-phase reduction
-    uint32_t max_chunk = (a.C + ATTN_NSPLIT_MAX - 1) / ATTN_NSPLIT_MAX;
-    if (max_chunk < ATTN_MIN_CHUNK) max_chunk = ATTN_MIN_CHUNK;
+    uint32_t max_chunk = (a.C + p.max_split - 1) / p.max_split;
+    if (max_chunk < p.min_chunk) max_chunk = p.min_chunk;
     if (max_chunk > ATTN_MAX_CHUNK) return hipErrorInvalidValue;  // C <= 32768 positions
     max_chunk = (max_chunk + 3) & ~3u;
     if (max_chunk < 2 * ATTN_NSPLIT_MAX) max_chunk = 2 * ATTN_NSPLIT_MAX;
     const uint32_t lpp = a.D / 4, ngrp = ATTN_BLOCK / lpp;
     const size_t lds = (64 + (size_t)G * max_chunk + (size_t)G * ngrp * a.D + 64) * sizeof(float);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    const dim3 grid(a.Hkv, ATTN_NSPLIT_MAX);
+    const dim3 grid(a.Hkv, p.max_split);
     const bool f16 = a.kv_type == NFAI_F16;
     if (a.D == 64) return f16 ? launch_g<16, true>(p, G, grid, lds, s) : launch_g<16, false>(p, G, grid, lds, s);
     return f16 ? launch_g<32, true>(p, G, grid, lds, s) : launch_g<32, false>(p, G, grid, lds, s);

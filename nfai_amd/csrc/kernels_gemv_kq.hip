@@ -21,6 +21,8 @@
 //        8 B of qh, the 8 scale bytes of its half and d.
 // The activations are staged in LDS in the order the lanes consume them, so that every
 // ds_read_b128 of a wave covers 64 consecutive 16-byte slots (conflict-free).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -457,7 +459,10 @@ static hipError_t kq_upw(const KqParams &p, int upw, uint32_t grid, uint32_t blo
     constexpr int RPU = (MODE == GEMV_QKV_ROPE || MODE == GEMV_GATEUP) ? 2 : 1;
     if (upw == 1) return kq_launch<QT, MODE, 1>(p, grid, block, lds, s);
     if (upw == 2) return kq_launch<QT, MODE, 2>(p, grid, block, lds, s);
-    if constexpr (RPU == 1) return kq_launch<QT, MODE, 4>(p, grid, block, lds, s);
+    if constexpr (RPU == 1) {
+        if (upw == 3) return kq_launch<QT, MODE, 3>(p, grid, block, lds, s);
+        return kq_launch<QT, MODE, 4>(p, grid, block, lds, s);
+    }
     return hipErrorInvalidValue;
 }
 
@@ -515,13 +520,17 @@ hipError_t launch_gemv_kq(const GemvArgs &a, hipStream_t s)
     uint32_t grid = n_cu;
     if (!exact && p.NU < n_cu * 8) { grid = (p.NU + 7) / 8; wpb = 8; }
     if (grid == 0) grid = 1;
+    static const int env_bpc = getenv("NFAI_KQ_BPC") ? atoi(getenv("NFAI_KQ_BPC")) : 0;   // sweep knobs
+    static const int env_wpb = getenv("NFAI_KQ_WPB") ? atoi(getenv("NFAI_KQ_WPB")) : 0;
+    if (env_wpb >= 1 && env_wpb <= 8 && p.NU >= n_cu * 16) wpb = (uint32_t)env_wpb;
+    if (env_bpc >= 1 && env_bpc <= 4 && p.NU >= n_cu * 16) grid = n_cu * (uint32_t)env_bpc;
     const uint32_t xn = a.gamma ? 4 : 16;
     const uint32_t kpad = p.KC * 2048;
     while (wpb < 8 && (uint64_t)xn * wpb * 64 * 4 < kpad) wpb++;
     if ((uint64_t)xn * wpb * 64 * 4 < kpad) return hipErrorInvalidValue;
     const uint32_t upw_total = (p.NU + grid * wpb - 1) / (grid * wpb);
     int upw = 1;
-    for (int c : {4, 2, 1})  // <= 4 rows per step: two register buffers of 8-9 dwords per row must not spill
+    for (int c : {4, 3, 2, 1})  // <= 4 rows per step: two register buffers of 8-9 dwords per row must not spill
         if (c * rpu <= 4 && upw_total % c == 0) { upw = c; break; }
     const size_t lds = ((size_t)kpad + (size_t)p.KC * 128 + 16) * sizeof(float);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
