@@ -74,7 +74,8 @@ uint64_t weight_row_bytes(int t, uint64_t n_cols)
     switch (t) {
         case NFAI_F32: return n_cols * 4;
         case NFAI_F16: return n_cols % 8 == 0 ? n_cols * 2 : 0;
-        case NFAI_Q4_K: return n_cols % 256 == 0 ? n_cols / 256 * 144 : 0;
+        case NFAI_Q4_K:
+        case NFAI_Q4_K_T16: return n_cols % 256 == 0 ? n_cols / 256 * 144 : 0;
         case NFAI_Q6_K: return n_cols % 256 == 0 ? n_cols / 256 * 210 : 0;
     }
     return 0;
@@ -317,15 +318,37 @@ NFAI_API int32_t nfai_hip_weight_upload(nfai_ctx_t h, int32_t type, uint64_t n_r
     if (rc) return rc;
     rc = nfai_hip_buf_alloc(h, bytes, out);
     if (rc) return rc;
-    if (type != NFAI_Q6_K) return nfai_hip_buf_upload(h, *out, 0, host, bytes);
-    // Q6_K: 210-byte native blocks are repacked into the aligned plane layout the kernels read
+    const bool q4_t16 = type == NFAI_Q4_K && n_rows > 0 && n_rows % 16 == 0;
+    if (type != NFAI_Q6_K && !q4_t16) return nfai_hip_buf_upload(h, *out, 0, host, bytes);
+    // Q6_K: 210-byte native blocks are repacked into the aligned plane layout the kernels read;
+    // Q4_K with a multiple of 16 rows: into the T16 tile layout of kernels_gemv_kqm.hip
     nfai_buf_t tmp = 0;
     if ((rc = nfai_hip_buf_alloc(h, bytes, &tmp))) return rc;
     if ((rc = nfai_hip_buf_upload(h, tmp, 0, host, bytes))) return rc;
     Ctx *c = ctx_of(h);
-    hipError_t e = launch_repack_q6k(buf_of(tmp)->ptr, buf_of(*out)->ptr, n_rows * n_cols / 256, c->stream);
-    if (e != hipSuccess) return fail(NFAI_ERR_HIP, "weight_upload: Q6_K repack failed: %s", hipGetErrorString(e));
+    hipError_t e;
+    if (q4_t16) {
+        e = launch_repack_q4k_t16(buf_of(tmp)->ptr, buf_of(*out)->ptr, n_rows, n_cols, c->stream);
+        buf_of(*out)->w_layout = NFAI_Q4_K_T16;
+        buf_of(*out)->w_rows = n_rows;
+    } else {
+        e = launch_repack_q6k(buf_of(tmp)->ptr, buf_of(*out)->ptr, n_rows * n_cols / 256, c->stream);
+    }
+    if (e != hipSuccess) return fail(NFAI_ERR_HIP, "weight_upload: K-quant repack failed: %s", hipGetErrorString(e));
     return nfai_hip_buf_free(h, tmp);
+}
+
+// A weight buffer that nfai_hip_weight_upload repacked keeps its internal layout code; the ops must then be
+// given the whole tensor (the T16 planes are addressed by its row count).
+static int resolve_layout(const char *fn, const Buf *w, int type, uint64_t rows, int *out)
+{
+    *out = type;
+    if (w->w_layout == 0 || ggml_type_of(w->w_layout) != type) return NFAI_OK;
+    if (w->w_rows != rows)
+        return fail(NFAI_ERR_INVALID, "%s: weight buffer was uploaded with %llu rows (tiled layout), the call uses %llu", fn,
+                    (unsigned long long)w->w_rows, (unsigned long long)rows);
+    *out = w->w_layout;
+    return NFAI_OK;
 }
 
 // ---- 1:1 operators ---------------------------------------------------------------------------
@@ -345,7 +368,9 @@ NFAI_API int32_t nfai_hip_embed(nfai_ctx_t h, nfai_buf_t table, int32_t type, nf
     if (type == NFAI_Q4_K || type == NFAI_Q6_K) {
         const uint64_t rb = weight_row_bytes(type, E);
         if (rb == 0) return fail(NFAI_ERR_UNSUPPORTED, "embed: K-quant table needs E %% 256 == 0 (E=%u)", E);
-        LAUNCH_TRY(launch_embed_kq(bt->ptr, type, bt->bytes / rb, static_cast<const uint32_t *>(bk->ptr), static_cast<float *>(by->ptr), E, c->stream));
+        int lt;
+        { int rc = resolve_layout(__func__, bt, type, bt->bytes / rb, &lt); if (rc) return rc; }
+        LAUNCH_TRY(launch_embed_kq(bt->ptr, lt, bt->bytes / rb, static_cast<const uint32_t *>(bk->ptr), static_cast<float *>(by->ptr), E, c->stream));
         return NFAI_OK;
     }
     if (type != NFAI_F16 && type != NFAI_F32) return fail(NFAI_ERR_UNSUPPORTED, "embed: table type %d", type);
@@ -392,7 +417,7 @@ NFAI_API int32_t nfai_hip_gemv(nfai_ctx_t h, nfai_buf_t W, int32_t type, nfai_bu
     GemvArgs a;
     a.W[0] = bw->ptr;
     a.seg_rows[0] = N;
-    a.w_type = type;
+    { int rc = resolve_layout(__func__, bw, type, N, &a.w_type); if (rc) return rc; }
     a.x = static_cast<const float *>(bx->ptr);
     a.K = K;
     a.mode = GEMV_PLAIN;
@@ -564,7 +589,7 @@ NFAI_API int32_t nfai_hip_gemv_fused(nfai_ctx_t h, nfai_buf_t W, int32_t type, n
     GemvArgs a;
     a.W[0] = bw->ptr;
     a.seg_rows[0] = N;
-    a.w_type = type;
+    { int rc = resolve_layout(__func__, bw, type, N, &a.w_type); if (rc) return rc; }
     a.x = static_cast<const float *>(bx->ptr);
     a.gamma = bg ? static_cast<const float *>(bg->ptr) : nullptr;
     a.eps = eps;
@@ -596,7 +621,12 @@ NFAI_API int32_t nfai_hip_gemv_gateup_silu(nfai_ctx_t h, nfai_buf_t Wg, nfai_buf
     a.W[0] = bg_->ptr;
     a.W[1] = bu->ptr;
     a.seg_rows[0] = a.seg_rows[1] = F;
-    a.w_type = type;
+    {
+        int t0, t1, rc;
+        if ((rc = resolve_layout(__func__, bg_, type, F, &t0)) || (rc = resolve_layout(__func__, bu, type, F, &t1))) return rc;
+        if (t0 != t1) return fail(NFAI_ERR_INVALID, "%s: gate and up weights were uploaded in different layouts", __func__);
+        a.w_type = t0;
+    }
     a.x = static_cast<const float *>(bx->ptr);
     a.gamma = bg ? static_cast<const float *>(bg->ptr) : nullptr;
     a.eps = eps;
@@ -643,7 +673,14 @@ NFAI_API int32_t nfai_hip_gemv_qkv_rope(nfai_ctx_t h, nfai_buf_t Wq, nfai_buf_t 
     GemvArgs a;
     a.W[0] = bq_->ptr; a.W[1] = bk_->ptr; a.W[2] = bv_->ptr;
     a.seg_rows[0] = H * D; a.seg_rows[1] = Hkv * D; a.seg_rows[2] = Hkv * D;
-    a.w_type = type;
+    {
+        int t0, t1, t2, rc;
+        if ((rc = resolve_layout(__func__, bq_, type, H * D, &t0)) || (rc = resolve_layout(__func__, bk_, type, Hkv * D, &t1)) ||
+            (rc = resolve_layout(__func__, bv_, type, Hkv * D, &t2)))
+            return rc;
+        if (t0 != t1 || t0 != t2) return fail(NFAI_ERR_INVALID, "%s: q, k, v weights were uploaded in different layouts", __func__);
+        a.w_type = t0;
+    }
     a.x = static_cast<const float *>(bx->ptr);
     a.gamma = bg ? static_cast<const float *>(bg->ptr) : nullptr;
     a.eps = eps;

@@ -1,0 +1,509 @@
+// kernels_gemv_kqm.hip — decode GEMV on ggml K-quant weights, second generation: the dequantised
+// nibbles are multiplied with the activations on the matrix cores (v_mfma_f32_16x16x32_f16 used as
+// 64 independent 8-wide dot products per instruction), the K-quant scales are applied in fp32.
+// Same op as kernels_gemv_kq.hip (MatrixMultiplyShader.cs:255-289 on weights the reference cannot
+// load at all, Parser.cs:111-114); that file stays as the path for row counts that are not a
+// multiple of 16.
+//
+// Why: kernels_gemv_kq.hip spends ~2.8 VALU operations per weight and lane (cvt + fma per nibble,
+// eight ds_read_b128 of activations per 32 weights) and runs at 1.8 TB/s on the gate/up matrix of
+// Llama-3.2-3B — VALU/LDS-bound at a quarter of what HBM delivers.  Here a nibble pair becomes a
+// packed fp16 pair with ONE v_and_or_b32 (0x5400 | nibble << 4 = 64 + nibble exactly), the
+// multiply-accumulate moves to MFMA, and the activations are read from LDS by 8 lanes per
+// instruction instead of 64: ~1.5 VALU operations per weight and lane.
+//
+// Numerics: fp32 activations are split x*2^S = xh + xl/2048 into two fp16 values (S puts the largest
+// |x| near 2^13, so nothing on the path is an fp16 subnormal; 22 mantissa bits survive), the
+// integer weights (64 + q) are exact in fp16, products and sums are fp32 inside the MFMA; the offset
+// 64 * sum(xh + xl/2048) is subtracted in fp32.  Differences to the fp32 oracle are at the level of
+// fp32 summation-order noise (tests/test_gpu_kquant.py states the tolerance).
+//
+// HBM layout ("T16", repacked once at upload, same bytes): rows are grouped in tiles of 16.
+//   Q4_K: plane 0  [tile][blk][h:2][lane:64][16 B]  lane = G*16 + r holds qs[32G+16h .. +16) of row 16*tile+r,
+//                  i.e. lane group G owns sub-blocks 2G (low nibbles) and 2G+1 (high nibbles) of its row;
+//         plane 1  [tile][blk][r:16][16 B]          d, dmin, 12 scale bytes of row 16*tile+r.
+// Every wave-wide load is one contiguous kilobyte (qs) or 256 bytes (headers).
+//
+// Work split: a workgroup owns whole 16-row tiles ("units": one tile, or the gate and the up tile of
+// the same rows); its waves split K (wave w owns super-blocks w*BPW .. w*BPW+BPW-1 of every tile),
+// partial sums meet in LDS every UB units.  MFMA operand roles: A = activations (rows 4G / 4G+1 of
+// the 16x32 A matrix carry xh / xl for the k-slots of lane group G, zero elsewhere), B = weights
+// (column r = row r of the tile), so D[4G + {0,1}][r] lands in registers 0,1 of lane (G, r): every
+// lane receives the dot product of exactly the 8 weights it dequantised.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace nfai {
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct KqmParams {
+    const uint8_t *W[3];
+    uint32_t seg_tiles[3];     // 16-row tiles per segment
+    uint32_t seg_tile_end[3];  // running sum (QKV unit -> segment)
+    const float *x;
+    const float *gamma;
+    float eps;
+    uint32_t K, NB, NU, UB;
+    float *y;
+    const float *res;
+    void *kc, *vc;
+    uint64_t kv_pos_stride, kv_head_stride;
+    const float *rope_cs;
+    uint32_t rope_dims, D;
+    const uint32_t *pos;
+    int kv_f16;
+};
+
+struct Q4T { u32x4 q0, q1, hdr; };
+
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t bits) { return (a & mask) | bits; }
+
+__device__ __forceinline__ float dpp_add8(float v)  // sum within aligned groups of 8 lanes
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    return v;
+}
+
+template <int MODE>
+__device__ __forceinline__ void kqm_unit(const KqmParams &p, uint32_t u, int t, uint32_t &seg, uint32_t &tile)
+{
+    if constexpr (MODE == GEMV_GATEUP) {
+        seg = t; tile = u;
+    } else if constexpr (MODE == GEMV_QKV_ROPE) {
+        if (u < p.seg_tile_end[0]) { seg = 0; tile = u; }
+        else if (u < p.seg_tile_end[1]) { seg = 1; tile = u - p.seg_tile_end[0]; }
+        else { seg = 2; tile = u - p.seg_tile_end[1]; }
+    } else {
+        seg = 0; tile = u;
+    }
+}
+
+__device__ __forceinline__ Q4T q4t_load(const KqmParams &p, uint32_t seg, uint32_t tile, uint32_t blk, uint32_t lane)
+{
+    const uint64_t tb = (uint64_t)tile * p.NB + blk;
+    const uint64_t nblk = (uint64_t)p.seg_tiles[seg] * 16 * p.NB;
+    const uint8_t *base = p.W[seg];
+    Q4T r;
+    r.q0 = load_nt16(base + tb * 2048 + lane * 16);
+    r.q1 = load_nt16(base + tb * 2048 + 1024 + lane * 16);
+    r.hdr = load_nt16(base + nblk * 128 + tb * 256 + (lane & 15) * 16);
+    return r;
+}
+
+// 64 weights of one lane (sub-blocks 2G: low nibbles, 2G+1: high nibbles) against the activations.
+// abase: this lane's A-fragment base in LDS (zero page for the lanes whose A rows are zero);
+// sums = {SX[2G], SX[2G+1]} of this super-block.
+__device__ __forceinline__ float q4t_dot(const Q4T &w, const uint8_t *abase, f32x2 sums, uint32_t g)
+{
+    constexpr uint32_t M = 0x0F0F0F0Fu;
+    i32x4 dlo = {0, 0, 0, 0}, dhi = {0, 0, 0, 0};
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+        const u32x4 q = hf ? w.q1 : w.q0;
+        const u32x4 blo = q & M, bhi = (q >> 4) & M;  // 16 weights each, one byte per weight, k-slot j = byte j
+        const i32x4 alo = *reinterpret_cast<const i32x4 *>(abase + (0 * 2 + hf) * 256);
+        const i32x4 ahi = *reinterpret_cast<const i32x4 *>(abase + (1 * 2 + hf) * 256);
+        dlo = __builtin_amdgcn_mfma_i32_16x16x64_i8(alo, __builtin_bit_cast(i32x4, blo), dlo, 0, 0, 0);
+        dhi = __builtin_amdgcn_mfma_i32_16x16x64_i8(ahi, __builtin_bit_cast(i32x4, bhi), dhi, 0, 0, 0);
+    }
+    // get_scale_min_k4 (ggml) for sub-blocks 2G and 2G+1, branch-free (see kernels_gemv_kq.hip)
+    const float d = h2f_lo(w.hdr[0]), dmin = h2f_hi(w.hdr[0]);
+    float scv[2], mv[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t sb = 2 * g + h, sh = (sb & 3) * 8;
+        const uint32_t lo8 = (w.hdr[1] >> sh) & 0xFFu, mid = (w.hdr[2] >> sh) & 0xFFu, hi8 = (w.hdr[3] >> sh) & 0xFFu;
+        const bool low = sb < 4;
+        const uint32_t sc = low ? (lo8 & 63u) : ((hi8 & 0xFu) | ((lo8 >> 6) << 4));
+        const uint32_t mn = low ? (mid & 63u) : ((hi8 >> 4) | ((mid >> 6) << 4));
+        scv[h] = d * (float)sc;
+        mv[h] = dmin * (float)mn;
+    }
+    // three signed base-256 digits of the fixed-point activations: sum q*x' = S0 + 256*S1 + 65536*S2 (integers, exact)
+    const float vlo = fmaf((float)dlo[2], 65536.0f, fmaf((float)dlo[1], 256.0f, (float)dlo[0]));
+    const float vhi = fmaf((float)dhi[2], 65536.0f, fmaf((float)dhi[1], 256.0f, (float)dhi[0]));
+    float a = scv[0] * vlo;
+    a = fmaf(-mv[0], sums[0], a);
+    a = fmaf(scv[1], vhi, a);
+    a = fmaf(-mv[1], sums[1], a);
+    return a;
+}
+
+__device__ __forceinline__ void kqm_kv_store(void *base, int f16, uint64_t idx, float v)
+{
+    if (f16) reinterpret_cast<_Float16 *>(base)[idx] = (_Float16)v;
+    else reinterpret_cast<float *>(base)[idx] = v;
+}
+
+// lanes 0..15 hold the 16 rows of the unit (a0; a1 = up row for GATEUP)
+template <int MODE>
+__device__ __forceinline__ void kqm_epilogue(const KqmParams &p, uint32_t u, uint32_t lane, float a0, float a1)
+{
+    const uint32_t r = lane & 15;
+    if constexpr (MODE == GEMV_PLAIN) {
+        if (lane < 16) p.y[u * 16 + r] = a0;
+    } else if constexpr (MODE == GEMV_RESIDUAL) {
+        if (lane < 16) p.y[u * 16 + r] = p.res[u * 16 + r] + a0;
+    } else if constexpr (MODE == GEMV_GATEUP) {
+        if (lane < 16) p.y[u * 16 + r] = a1 * silu_ref(a0);
+    } else {
+        uint32_t seg, tile;
+        kqm_unit<MODE>(p, u, 0, seg, tile);
+        const uint32_t row = tile * 16 + r, head = row / p.D, dd = row % p.D;
+        const float other = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a0), 0xB1, 0xF, 0xF, true));
+        float o = a0;
+        const uint32_t de = dd & ~1u;  // the even element of the rotated pair
+        if (seg < 2 && de < p.rope_dims) {
+            const float c = p.rope_cs[de], sn = p.rope_cs[de + 1];
+            o = (dd & 1) ? (sn * other + c * a0) : (c * a0 - sn * other);
+        }
+        if (lane < 16) {
+            if (seg == 0) p.y[row] = o;
+            else kqm_kv_store(seg == 1 ? p.kc : p.vc, p.kv_f16, (uint64_t)p.pos[0] * p.kv_pos_stride + (uint64_t)head * p.kv_head_stride + dd, o);
+        }
+    }
+}
+
+// Two steps in flight per wave (ping-pong).  Measured alternatives, both slower on Llama-3.2-3B Q4_K_M
+// (714 tok/s with this shape): four buffers with conditional issues in the tail -> hipcc falls back to
+// s_waitcnt vmcnt(0) before the first consume (673 tok/s); four buffers with unconditional, clamped issues
+// past the end -> the surplus loads (non-temporal, so L2 not L1 hits) delay the short kernels (622 tok/s).
+// NS > 0: no workgroup has more than NS steps — all of them are issued before the prologue and consumed
+// in a straight line (the common case for the per-block matrices of a 3B model: 1-4 steps per wave).
+template <int MODE, int BPW, bool NORM, int NS>
+__global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_q4t(const KqmParams p)
+{
+    constexpr int R = MODE == GEMV_GATEUP ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
+    const uint32_t wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t kpad = nw * BPW * 256;
+    const uint32_t UB = p.UB & 0xFFu;
+    uint8_t *xa = smem;                                               // kpad * 4 bytes: A fragments [blk][n][m][G][hl][8 x fp16]
+    float *sums = reinterpret_cast<float *>(smem + (size_t)kpad * 4);  // [blk][G] x {SX of sub-block 2G, of 2G+1} (+ pad)
+    uint8_t *zero = reinterpret_cast<uint8_t *>(sums + nw * BPW * 16);  // 1 KB of zeros
+    float *red = reinterpret_cast<float *>(zero + 1024);              // [2][UB][R][nw][64]
+    float *scal = red + 2 * UB * R * nw * 64;                       // 32 floats of reduction scratch
+
+    const uint32_t nunits = (p.NU - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const uint32_t nsteps = nunits * R * BPW;  // step = (unit, tile of the unit, super-block of this wave)
+
+    // ---- activations first (vmcnt is in order: what the prologue needs must not queue behind weights)
+    f32x4 xv[BPW], gv[NORM ? BPW : 1];
+#pragma unroll
+    for (int i = 0; i < BPW; i++) {
+        const uint32_t k = (tid + i * blockDim.x) * 4;
+        const uint32_t kk = min(k, p.K - 4);
+        const f32x4 v = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.x + kk);
+        xv[i] = k < p.K ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (NORM) gv[i] = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.gamma + kk);
+    }
+
+    // Every wave of the workgroup has its activation loads in the memory pipeline before any wave queues
+    // weights behind them (the pipeline is shared in order: a late wave's x would otherwise wait behind the
+    // early waves' kilobytes of weights, and the prologue needs the x of ALL waves).  s_barrier only: no waitcnt.
+    if (p.UB & 0x100u) __builtin_amdgcn_s_barrier();
+    // ---- weights of the first steps
+    constexpr int NBUF = NS > 0 ? NS : 2;
+    Q4T buf[NBUF];
+    uint32_t ist = 0;
+    auto issue = [&](Q4T &buf) {
+        const uint32_t is = min(ist, nsteps - 1);  // past the end: the wave's own last step again
+        const uint32_t ui = is / (R * BPW), tt = (is / BPW) % R, bi = is % BPW;
+        const uint32_t u = blockIdx.x + ui * gridDim.x;
+        const uint32_t blk = min(wid * BPW + bi, p.NB - 1);
+        uint32_t seg, tile;
+        kqm_unit<MODE>(p, u, tt, seg, tile);
+        buf = q4t_load(p, seg, tile, blk, lane);
+        ++ist;
+    };
+#pragma unroll
+    for (int j = 0; j < NBUF; j++) issue(buf[j]);
+
+    // ---- prologue: RMSNorm, power-of-two scale, fp16 hi/lo split -> LDS, sub-block sums
+    float inv_scale;
+    {
+        float ss = 0.f, am = 0.f;
+#pragma unroll
+        for (int i = 0; i < BPW; i++) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                ss = fmaf(xv[i][e], xv[i][e], ss);
+                am = fmaxf(am, fabsf(NORM ? xv[i][e] * gv[i][e] : xv[i][e]));
+            }
+        }
+        ss = wave_sum(ss);
+        am = wave_max(am);
+        if (lane == 0) { scal[wid] = ss; scal[16 + wid] = am; }
+        if (tid < 64) *reinterpret_cast<u32x4 *>(zero + tid * 16) = u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();
+        float tss = 0.f, tam = 0.f;
+        for (uint32_t i = 0; i < nw; i++) { tss += scal[i]; tam = fmaxf(tam, scal[16 + i]); }
+        float rms = 1.f;
+        if constexpr (NORM) {
+            rms = sqrtf(tss / (float)p.K + p.eps);
+            tam = tam / rms;
+        }
+        int S = 0;
+        if (tam > 0.f && tam < 3.0e38f) S = 21 - ilogbf(tam);  // |x * 2^S| < 2^22: a 24-bit signed integer after rounding
+        S = max(-100, min(100, S));
+        const float scale = ldexpf(1.0f, S);
+        inv_scale = ldexpf(1.0f, -S);
+#pragma unroll
+        for (int i = 0; i < BPW; i++) {
+            const uint32_t k = (tid + i * blockDim.x) * 4;
+            f32x4 v = xv[i];
+            if constexpr (NORM) {
+                v[0] = (v[0] / rms) * gv[i][0];
+                v[1] = (v[1] / rms) * gv[i][1];
+                v[2] = (v[2] / rms) * gv[i][2];
+                v[3] = (v[3] / rms) * gv[i][3];
+            }
+            uint32_t d0 = 0, d1 = 0, d2 = 0;  // digit planes of the four elements, one byte each
+            float sx = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float vs = v[e] * scale;
+                const int xi = (int)rintf(vs);
+                const int b0 = (int)(int8_t)(xi & 0xFF);
+                const int r1 = (xi - b0) >> 8;
+                const int b1 = (int)(int8_t)(r1 & 0xFF);
+                const int b2 = (r1 - b1) >> 8;
+                d0 |= (uint32_t)(b0 & 0xFF) << (8 * e);
+                d1 |= (uint32_t)(b1 & 0xFF) << (8 * e);
+                d2 |= (uint32_t)(b2 & 0xFF) << (8 * e);
+                sx += (float)xi;
+            }
+            // element k = blk*256 + sb*32 + hf*16 + j: A fragment [blk][n][hf][G][digit][16 bytes], sb = 2G + n
+            const uint32_t blk = k >> 8, sb = (k >> 5) & 7, hf = (k >> 4) & 1, j = k & 15, g = sb >> 1, n = sb & 1;
+            uint8_t *frag = xa + (size_t)blk * 1024 + ((n * 2 + hf) * 4 + g) * 64 + j;
+            *reinterpret_cast<uint32_t *>(frag) = d0;
+            *reinterpret_cast<uint32_t *>(frag + 16) = d1;
+            *reinterpret_cast<uint32_t *>(frag + 32) = d2;
+            sx = dpp_add8(sx);
+            if ((lane & 7) == 0) sums[(blk * 4 + g) * 4 + n] = sx;
+        }
+        __syncthreads();
+    }
+
+    const uint32_t g = lane >> 4, ra = lane & 15;
+    const bool a_live = (ra >> 2) == g && (ra & 3) < 3;  // A rows 4G, 4G+1, 4G+2 = digits 0, 1, 2 of lane group G
+    const uint32_t a_off = g * 64 + (ra & 3) * 16;
+
+    float acc = 0.f;
+    uint32_t cst = 0, par = 0;
+    auto consume = [&](Q4T &buf) {
+        const uint32_t ui = cst / (R * BPW), tt = (cst / BPW) % R, bi = cst % BPW;
+        const uint32_t bc = wid * BPW + bi;
+        const bool live = bc < p.NB;
+        const uint32_t blk = min(bc, p.NB - 1);
+        const uint8_t *abase = a_live ? xa + (size_t)blk * 1024 + a_off : zero;
+        const f32x2 sm = *reinterpret_cast<const f32x2 *>(sums + (blk * 4 + g) * 4);
+        const float a = q4t_dot(buf, abase, sm, g);
+        acc += live ? a : 0.f;
+        ++cst;
+        if (bi == BPW - 1) {
+            const uint32_t slot = ui % UB;
+            red[(((par * UB + slot) * R + tt) * nw + wid) * 64 + lane] = acc;
+            acc = 0.f;
+            if (tt == R - 1 && (slot == UB - 1 || ui == nunits - 1)) {
+                __syncthreads();
+                if (wid <= slot) {  // wave q finishes unit q of this round
+                    const uint32_t uq = blockIdx.x + (ui - slot + wid) * gridDim.x;
+                    float af[R];
+#pragma unroll
+                    for (int t2 = 0; t2 < R; t2++) {
+                        const float *rp = red + (((par * UB + wid) * R + t2) * nw) * 64 + lane;
+                        float s = 0.f;
+                        for (uint32_t w = 0; w < nw; w++) s += rp[w * 64];
+                        s += __shfl_xor(s, 16);
+                        s += __shfl_xor(s, 32);
+                        af[t2] = s * inv_scale;
+                    }
+                    kqm_epilogue<MODE>(p, uq, lane, af[0], af[R - 1]);
+                }
+                par ^= 1;
+            }
+        }
+    };
+
+    if constexpr (NS > 0) {
+#pragma unroll
+        for (int j = 0; j < NS; j++)
+            if ((uint32_t)j < nsteps) consume(buf[j]);
+    } else {
+        uint32_t st = 0;
+        for (; st + 3 < nsteps; st += 2) {
+            consume(buf[0]);
+            issue(buf[0]);
+            consume(buf[1]);
+            issue(buf[1]);
+        }
+        const uint32_t rem = nsteps - st;
+        if (rem == 3) {
+            consume(buf[0]);
+            issue(buf[0]);
+            consume(buf[1]);
+            consume(buf[0]);
+        } else if (rem == 2) {
+            consume(buf[0]);
+            consume(buf[1]);
+        } else if (rem == 1) {
+            consume(buf[0]);
+        }
+    }
+}
+
+// ---- Q4_K repack: native 144-byte blocks (row-major) -> T16 planes (same bytes) ------------------------
+__global__ void k_repack_q4k_t16(const uint8_t *src, uint8_t *dst, uint32_t n_tiles, uint32_t NB)
+{
+    const uint64_t tb = blockIdx.x;  // tile * NB + blk
+    const uint32_t tile = (uint32_t)(tb / NB), blk = (uint32_t)(tb % NB), t = threadIdx.x;
+    const uint64_t nblk = (uint64_t)n_tiles * 16 * NB;
+    if (t < 128) {
+        const uint32_t h = t >> 6, ln = t & 63, G = ln >> 4, r = ln & 15;
+        const uint8_t *s = src + ((uint64_t)(tile * 16 + r) * NB + blk) * 144 + 16 + 32 * G + 16 * h;
+        *reinterpret_cast<u32x4 *>(dst + tb * 2048 + h * 1024 + ln * 16) = *reinterpret_cast<const u32x4 *>(s);
+    } else if (t < 144) {
+        const uint32_t r = t - 128;
+        const uint8_t *s = src + ((uint64_t)(tile * 16 + r) * NB + blk) * 144;
+        *reinterpret_cast<u32x4 *>(dst + nblk * 128 + tb * 256 + r * 16) = *reinterpret_cast<const u32x4 *>(s);
+    }
+}
+
+hipError_t launch_repack_q4k_t16(const void *native, void *tiled, uint64_t rows, uint64_t cols, hipStream_t s)
+{
+    if (rows == 0) return hipSuccess;
+    if (rows % 16 || cols % 256) return hipErrorInvalidValue;
+    const uint64_t nb = cols / 256, grid = rows / 16 * nb;
+    if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    k_repack_q4k_t16<<<(uint32_t)grid, 192, 0, s>>>(static_cast<const uint8_t *>(native), static_cast<uint8_t *>(tiled), (uint32_t)(rows / 16),
+                                                    (uint32_t)nb);
+    return hipGetLastError();
+}
+
+// ---- one row of a T16 table -> fp32 (embedding gather) ----------------------------------------------------
+__global__ void k_embed_q4t(const uint8_t *table, uint64_t n_rows, const uint32_t *tok, float *y, uint32_t E)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= E) return;
+    const uint32_t NB = E / 256, blk = k >> 8, kk = k & 255, sb = kk >> 5, l = kk & 31;
+    const uint64_t row = tok[0], tile = row >> 4, r = row & 15, tb = tile * NB + blk, nblk = n_rows * NB;
+    const uint8_t *hdr = table + nblk * 128 + tb * 256 + r * 16;
+    const float d = (float)*reinterpret_cast<const _Float16 *>(hdr), dmin = (float)*reinterpret_cast<const _Float16 *>(hdr + 2);
+    const uint8_t *scales = hdr + 4;
+    uint32_t sc, m;
+    if (sb < 4) { sc = scales[sb] & 63; m = scales[sb + 4] & 63; }
+    else { sc = (scales[sb + 4] & 0xF) | ((scales[sb - 4] >> 6) << 4); m = (scales[sb + 4] >> 4) | ((scales[sb] >> 6) << 4); }
+    const uint8_t q = table[tb * 2048 + (l >> 4) * 1024 + ((sb >> 1) * 16 + r) * 16 + (l & 15)];
+    const float qv = (float)((sb & 1) ? (q >> 4) : (q & 0xF));
+    y[k] = d * (float)sc * qv - dmin * (float)m;
+}
+
+hipError_t launch_embed_kqt(const void *table, int type, uint64_t n_rows, const uint32_t *tok, float *y, uint32_t E, hipStream_t s)
+{
+    if (E % 256 || n_rows % 16 || type != NFAI_Q4_K_T16) return hipErrorInvalidValue;
+    k_embed_q4t<<<(E + 255) / 256, 256, 0, s>>>(static_cast<const uint8_t *>(table), n_rows, tok, y, E);
+    return hipGetLastError();
+}
+
+// ---- dispatch ------------------------------------------------------------------------------------------
+template <int MODE, int BPW>
+static hipError_t q4t_launch(const KqmParams &p, int ns, uint32_t grid, uint32_t block, size_t lds, hipStream_t s)
+{
+    auto go = [&](auto kern) {
+        static bool attr_done = false;  // per instantiation
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, p);
+        return hipGetLastError();
+    };
+    const bool norm = p.gamma != nullptr;
+    switch (ns) {
+        case 1: return norm ? go(k_gemv_q4t<MODE, BPW, true, 1>) : go(k_gemv_q4t<MODE, BPW, false, 1>);
+        case 2: return norm ? go(k_gemv_q4t<MODE, BPW, true, 2>) : go(k_gemv_q4t<MODE, BPW, false, 2>);
+        case 4: return norm ? go(k_gemv_q4t<MODE, BPW, true, 4>) : go(k_gemv_q4t<MODE, BPW, false, 4>);
+    }
+    return norm ? go(k_gemv_q4t<MODE, BPW, true, 0>) : go(k_gemv_q4t<MODE, BPW, false, 0>);
+}
+
+template <int MODE>
+static hipError_t q4t_bpw(const KqmParams &p, int bpw, uint32_t grid, uint32_t block, size_t lds, hipStream_t s)
+{
+    // steps of the busiest workgroup; all-upfront variants exist for 1, 2 and (<= 12 waves) 4 steps
+    constexpr int R = MODE == GEMV_GATEUP ? 2 : 1;
+    const uint32_t max_steps = (p.NU + grid - 1) / grid * R * bpw;
+    static const int env_ns = getenv("NFAI_KQM_NS") ? atoi(getenv("NFAI_KQM_NS")) : 1;
+    int ns = 0;
+    if (env_ns) {
+        if (max_steps == 1) ns = 1;
+        else if (max_steps == 2) ns = 2;
+        else if (env_ns >= 2 && max_steps <= 4 && block <= 768) ns = 4;  // measured slower than ping-pong (compute no longer overlaps the stream)
+    }
+    if (bpw == 1) return q4t_launch<MODE, 1>(p, ns, grid, block, lds, s);
+    if (bpw == 2) return q4t_launch<MODE, 2>(p, ns, grid, block, lds, s);
+    return q4t_launch<MODE, 4>(p, ns, grid, block, lds, s);
+}
+
+hipError_t launch_gemv_kqm(const GemvArgs &a, hipStream_t s)
+{
+    if (a.w_type != NFAI_Q4_K_T16) return hipErrorInvalidValue;
+    if (a.K == 0 || a.K % 256 != 0 || a.K > 16384) return hipErrorInvalidValue;
+    KqmParams p{};
+    uint32_t total_tiles = 0;
+    for (int i = 0; i < 3; i++) {
+        if (a.seg_rows[i] % 16) return hipErrorInvalidValue;
+        p.W[i] = reinterpret_cast<const uint8_t *>(a.W[i]);
+        p.seg_tiles[i] = a.seg_rows[i] / 16;
+        total_tiles += p.seg_tiles[i];
+        p.seg_tile_end[i] = total_tiles;
+    }
+    if (a.mode == GEMV_QKV_ROPE) {
+        if (a.D & 1u) return hipErrorInvalidValue;
+        p.NU = total_tiles;
+    } else if (a.mode == GEMV_GATEUP) {
+        if (a.seg_rows[0] != a.seg_rows[1]) return hipErrorInvalidValue;
+        p.NU = p.seg_tiles[0];
+    } else {
+        p.NU = p.seg_tiles[0];
+    }
+    if (p.NU == 0) return hipSuccess;
+    p.x = a.x; p.gamma = a.gamma; p.eps = a.eps; p.K = a.K;
+    p.NB = a.K / 256;
+    p.y = a.y; p.res = a.res; p.kc = a.kcache; p.vc = a.vcache;
+    p.kv_pos_stride = a.kv_pos_stride; p.kv_head_stride = a.kv_head_stride;
+    p.rope_cs = a.rope_cs; p.rope_dims = a.rope_dims; p.D = a.D ? a.D : 2; p.pos = a.pos_dev;
+    p.kv_f16 = a.kv_type == NFAI_F16;
+    const int bpw = p.NB <= 16 ? 1 : (p.NB <= 32 ? 2 : 4);
+    const uint32_t nw = (p.NB + bpw - 1) / bpw;
+    static const int env_bpc = getenv("NFAI_KQM_BPC") ? atoi(getenv("NFAI_KQM_BPC")) : 1;  // sweep knobs
+    static const int env_ub = getenv("NFAI_KQM_UB") ? atoi(getenv("NFAI_KQM_UB")) : 4;
+    const uint32_t grid = min(p.NU, a.n_cu * (uint32_t)max(1, min(env_bpc, 8)));
+    const uint32_t upb = (p.NU + grid - 1) / grid;
+    p.UB = min((uint32_t)max(1, min(env_ub, 8)), min(upb, nw));
+    const int R = a.mode == GEMV_GATEUP ? 2 : 1;
+    static const int env_xb = getenv("NFAI_KQM_XBAR") ? atoi(getenv("NFAI_KQM_XBAR")) : 0;
+    const size_t lds = (size_t)nw * bpw * 1024 + (size_t)nw * bpw * 64 + 1024 + (size_t)2 * p.UB * R * nw * 256 + 128;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (env_xb) p.UB |= 0x100u;  // experiment flag, see the kernel
+    switch (a.mode) {
+        case GEMV_PLAIN: return q4t_bpw<GEMV_PLAIN>(p, bpw, grid, nw * 64, lds, s);
+        case GEMV_RESIDUAL: return q4t_bpw<GEMV_RESIDUAL>(p, bpw, grid, nw * 64, lds, s);
+        case GEMV_QKV_ROPE: return q4t_bpw<GEMV_QKV_ROPE>(p, bpw, grid, nw * 64, lds, s);
+        case GEMV_GATEUP: return q4t_bpw<GEMV_GATEUP>(p, bpw, grid, nw * 64, lds, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace nfai

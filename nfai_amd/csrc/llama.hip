@@ -146,7 +146,7 @@ int check_shape(const char *what, const Tensor &t, uint64_t rows, uint64_t cols,
         return fail(NFAI_ERR_INVALID, "finalize: tensor %s is %llux%llu, expected %llux%llu", what, (unsigned long long)t.rows,
                     (unsigned long long)t.cols, (unsigned long long)rows, (unsigned long long)cols);
     if (!matrix && t.type != NFAI_F32) return fail(NFAI_ERR_UNSUPPORTED, "finalize: norm gain %s must be F32 (type %d)", what, t.type);
-    if (matrix && t.type != NFAI_F16 && t.type != NFAI_F32 && t.type != NFAI_Q4_K && t.type != NFAI_Q6_K)
+    if (matrix && t.type != NFAI_F16 && t.type != NFAI_F32 && !is_kquant(t.type))
         return fail(NFAI_ERR_UNSUPPORTED, "finalize: matrix %s has ggml type %d; kernels exist for F16/F32/Q4_K/Q6_K", what, t.type);
     return NFAI_OK;
 }
@@ -388,7 +388,7 @@ int enqueue_token(Model *m, bool with_head)
     hipStream_t s = m->ctx->stream;
     Rec rec{m};
     const uint32_t nfreq = (d.rope_dims < d.D ? d.rope_dims : d.D) / 2;
-    const bool emb_kq = m->token_embd.type == NFAI_Q4_K || m->token_embd.type == NFAI_Q6_K;
+    const bool emb_kq = is_kquant(m->token_embd.type);
     if (m->first_stage && emb_kq)
         K_TRY(KC_OTHER, launch_embed_kq(m->token_embd.ptr, m->token_embd.type, m->token_embd.rows, m->d_tok, m->x, d.E, s));
     K_TRY(KC_OTHER, launch_token_begin(m->first_stage && !emb_kq ? m->token_embd.ptr : nullptr, m->token_embd.type, m->d_tok, m->x, d.E,
@@ -624,8 +624,9 @@ static int set_tensor_impl(Model *m, const char *name, int type, uint64_t rows, 
                              (unsigned long long)cols);
     if (t->owned && t->ptr) { HIP_TRY(hipFree(t->ptr)); }
     t->type = type; t->rows = rows; t->cols = cols; t->bytes = rb * rows;
-    if (type == NFAI_Q6_K) {
-        // native 210-byte blocks (host or device) -> owned plane-layout copy (see common.h)
+    const bool q4_t16 = type == NFAI_Q4_K && rows > 0 && rows % 16 == 0;
+    if (type == NFAI_Q6_K || q4_t16) {
+        // native blocks (host or device) -> owned repacked copy: Q6_K planes (common.h), Q4_K T16 tiles (kernels_gemv_kqm.hip)
         void *native = dev;
         if (!dev) {
             if (!host) return fail(NFAI_ERR_INVALID, "set_tensor(%s): null data", name);
@@ -634,8 +635,10 @@ static int set_tensor_impl(Model *m, const char *name, int type, uint64_t rows, 
         }
         DALLOC(t->ptr, t->bytes);
         t->owned = true;
-        hipError_t e = launch_repack_q6k(native, t->ptr, rows * cols / 256, m->ctx->stream);
-        if (e != hipSuccess) return fail(NFAI_ERR_HIP, "set_tensor(%s): Q6_K repack failed: %s", name, hipGetErrorString(e));
+        hipError_t e = q4_t16 ? launch_repack_q4k_t16(native, t->ptr, rows, cols, m->ctx->stream)
+                              : launch_repack_q6k(native, t->ptr, rows * cols / 256, m->ctx->stream);
+        if (e != hipSuccess) return fail(NFAI_ERR_HIP, "set_tensor(%s): K-quant repack failed: %s", name, hipGetErrorString(e));
+        if (q4_t16) t->type = NFAI_Q4_K_T16;
         HIP_TRY(hipStreamSynchronize(m->ctx->stream));
         if (!dev) HIP_TRY(hipFree(native));
     } else if (dev) {
