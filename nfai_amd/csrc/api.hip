@@ -76,7 +76,8 @@ uint64_t weight_row_bytes(int t, uint64_t n_cols)
         case NFAI_F16: return n_cols % 8 == 0 ? n_cols * 2 : 0;
         case NFAI_Q4_K:
         case NFAI_Q4_K_T16: return n_cols % 256 == 0 ? n_cols / 256 * 144 : 0;
-        case NFAI_Q6_K: return n_cols % 256 == 0 ? n_cols / 256 * 210 : 0;
+        case NFAI_Q6_K:
+        case NFAI_Q6_K_T16: return n_cols % 256 == 0 ? n_cols / 256 * 210 : 0;
     }
     return 0;
 }
@@ -318,7 +319,8 @@ NFAI_API int32_t nfai_hip_weight_upload(nfai_ctx_t h, int32_t type, uint64_t n_r
     if (rc) return rc;
     rc = nfai_hip_buf_alloc(h, bytes, out);
     if (rc) return rc;
-    const bool q4_t16 = type == NFAI_Q4_K && n_rows > 0 && n_rows % 16 == 0;
+    const bool t16 = n_rows > 0 && n_rows % 16 == 0;
+    const bool q4_t16 = type == NFAI_Q4_K && t16, q6_t16 = type == NFAI_Q6_K && t16;
     if (type != NFAI_Q6_K && !q4_t16) return nfai_hip_buf_upload(h, *out, 0, host, bytes);
     // Q6_K: 210-byte native blocks are repacked into the aligned plane layout the kernels read;
     // Q4_K with a multiple of 16 rows: into the T16 tile layout of kernels_gemv_kqm.hip
@@ -330,6 +332,10 @@ NFAI_API int32_t nfai_hip_weight_upload(nfai_ctx_t h, int32_t type, uint64_t n_r
     if (q4_t16) {
         e = launch_repack_q4k_t16(buf_of(tmp)->ptr, buf_of(*out)->ptr, n_rows, n_cols, c->stream);
         buf_of(*out)->w_layout = NFAI_Q4_K_T16;
+        buf_of(*out)->w_rows = n_rows;
+    } else if (q6_t16) {
+        e = launch_repack_q6k_t16(buf_of(tmp)->ptr, buf_of(*out)->ptr, n_rows, n_cols, c->stream);
+        buf_of(*out)->w_layout = NFAI_Q6_K_T16;
         buf_of(*out)->w_rows = n_rows;
     } else {
         e = launch_repack_q6k(buf_of(tmp)->ptr, buf_of(*out)->ptr, n_rows * n_cols / 256, c->stream);

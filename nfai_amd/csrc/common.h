@@ -90,14 +90,15 @@ enum GemvMode { GEMV_PLAIN = 0, GEMV_RESIDUAL = 1, GEMV_QKV_ROPE = 2, GEMV_GATEU
 
 // Internal weight-type codes of the T16 layouts (kernels_gemv_kqm.hip): same bytes as the ggml type, rows
 // grouped in tiles of 16.  Never seen across the C ABI: uploads with rows % 16 == 0 are repacked into them.
-constexpr int NFAI_Q4_K_T16 = 112;
-inline bool is_kquant(int t) { return t == NFAI_Q4_K || t == NFAI_Q6_K || t == NFAI_Q4_K_T16; }
-inline int ggml_type_of(int t) { return t == NFAI_Q4_K_T16 ? NFAI_Q4_K : t; }
+constexpr int NFAI_Q4_K_T16 = 112, NFAI_Q6_K_T16 = 114;
+inline bool is_kquant(int t) { return t == NFAI_Q4_K || t == NFAI_Q6_K || t == NFAI_Q4_K_T16 || t == NFAI_Q6_K_T16; }
+inline int ggml_type_of(int t) { return t == NFAI_Q4_K_T16 ? NFAI_Q4_K : (t == NFAI_Q6_K_T16 ? NFAI_Q6_K : t); }
 
 hipError_t launch_gemv(const GemvArgs &a, hipStream_t s);     // any weight type; K-quants go to launch_gemv_kq / _kqm
 hipError_t launch_gemv_kq(const GemvArgs &a, hipStream_t s);  // Q4_K (native blocks) / Q6_K (plane layout)
 hipError_t launch_gemv_kqm(const GemvArgs &a, hipStream_t s); // Q4_K_T16: MFMA dot products
 hipError_t launch_repack_q4k_t16(const void *native, void *tiled, uint64_t rows, uint64_t cols, hipStream_t s);
+hipError_t launch_repack_q6k_t16(const void *native, void *tiled, uint64_t rows, uint64_t cols, hipStream_t s);
 hipError_t launch_embed_kqt(const void *table, int type, uint64_t n_rows, const uint32_t *tok, float *y, uint32_t E, hipStream_t s);
 // Q6_K super-blocks are 210 bytes (not 16-byte aligned): in HBM they live as four planes
 // ql | qh | scales | d (same bytes, naturally aligned accesses).  nblk = rows * cols / 256.

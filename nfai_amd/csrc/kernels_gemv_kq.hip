@@ -438,7 +438,7 @@ __global__ void k_embed_kq(const uint8_t *table, uint64_t n_rows, const uint32_t
 hipError_t launch_embed_kq(const void *table, int type, uint64_t n_rows, const uint32_t *tok, float *y, uint32_t E, hipStream_t s)
 {
     if (E % 256) return hipErrorInvalidValue;
-    if (type == NFAI_Q4_K_T16) return launch_embed_kqt(table, type, n_rows, tok, y, E, s);
+    if (type == NFAI_Q4_K_T16 || type == NFAI_Q6_K_T16) return launch_embed_kqt(table, type, n_rows, tok, y, E, s);
     if (type == NFAI_Q4_K) k_embed_kq<NFAI_Q4_K><<<(E + 255) / 256, 256, 0, s>>>(static_cast<const uint8_t *>(table), n_rows, tok, y, E);
     else if (type == NFAI_Q6_K) k_embed_kq<NFAI_Q6_K><<<(E + 255) / 256, 256, 0, s>>>(static_cast<const uint8_t *>(table), n_rows, tok, y, E);
     else return hipErrorInvalidValue;

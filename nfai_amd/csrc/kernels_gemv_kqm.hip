@@ -32,6 +32,8 @@
 // lane receives the dot product of exactly the 8 weights it dequantised.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace nfai {
@@ -137,6 +139,48 @@ __device__ __forceinline__ float q4t_dot(const Q4T &w, const uint8_t *abase, f32
     return a;
 }
 
+struct Q6T { u32x4 qla, qlb, qh, sc; uint32_t d; };
+
+__device__ __forceinline__ Q6T q6t_load(const KqmParams &p, uint32_t seg, uint32_t tile, uint32_t blk, uint32_t lane)
+{
+    const uint64_t tb = (uint64_t)tile * p.NB + blk;
+    const uint64_t nblk = (uint64_t)p.seg_tiles[seg] * 16 * p.NB;
+    const uint8_t *base = p.W[seg];
+    Q6T r;
+    r.qla = load_nt16(base + tb * 3072 + lane * 16);
+    r.qlb = load_nt16(base + tb * 3072 + 1024 + lane * 16);
+    r.qh = load_nt16(base + tb * 3072 + 2048 + lane * 16);
+    r.sc = load_nt16(base + nblk * 192 + tb * 256 + (lane & 15) * 16);
+    r.d = *reinterpret_cast<const GLOBAL_AS uint16_t *>((const GLOBAL_AS uint8_t *)base + nblk * 208 + tb * 32 + (lane & 15) * 2);
+    return r;
+}
+
+// 64 weights of one lane: half n = G>>1 of the super-block, columns l = 16*(G&1) .. +15 of all four quarters
+// (ggml dequantize_row_q6_K: quarter 0/2 = low/high nibbles of ql[l], quarter 1/3 = of ql[l+32], bits 2q..2q+1 of qh[l]);
+// one MFMA per quarter = one 16-weight scale group.  sums = sum of x' over each of the four groups.
+__device__ __forceinline__ float q6t_dot(const Q6T &w, const uint8_t *abase, f32x4 sums, uint32_t g)
+{
+    constexpr uint32_t M4 = 0x0F0F0F0Fu, M2 = 0x30303030u;
+    const float d = h2f_lo(w.d);
+    float tot = 0.f;
+#pragma unroll
+    for (int qd = 0; qd < 4; qd++) {
+        const u32x4 ql = (qd & 1) ? w.qlb : w.qla;
+        const u32x4 lo4 = (qd >= 2) ? ((ql >> 4) & M4) : (ql & M4);
+        const u32x4 hs = qd == 0 ? (w.qh << 4) : (qd == 1 ? (w.qh << 2) : (qd == 2 ? w.qh : (w.qh >> 2)));
+        const u32x4 b = (hs & M2) | lo4;  // unsigned 6-bit value per byte
+        const i32x4 a = *reinterpret_cast<const i32x4 *>(abase + qd * 256);
+        const i32x4 dq = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, __builtin_bit_cast(i32x4, b), i32x4{0, 0, 0, 0}, 0, 0, 0);
+        const float v = fmaf((float)dq[2], 65536.0f, fmaf((float)dq[1], 256.0f, (float)dq[0]));
+        // scales[8n + (G&1) + 2*qd] of the row
+        const uint32_t si = 8 * (g >> 1) + (g & 1) + 2 * qd;
+        const uint32_t sw = si < 8 ? (si < 4 ? w.sc[0] : w.sc[1]) : (si < 12 ? w.sc[2] : w.sc[3]);
+        const int sc = (int)(int8_t)((sw >> ((si & 3) * 8)) & 0xFFu);
+        tot = fmaf((float)sc, fmaf(-32.0f, sums[qd], v), tot);
+    }
+    return d * tot;
+}
+
 __device__ __forceinline__ void kqm_kv_store(void *base, int f16, uint64_t idx, float v)
 {
     if (f16) reinterpret_cast<_Float16 *>(base)[idx] = (_Float16)v;
@@ -178,9 +222,10 @@ __device__ __forceinline__ void kqm_epilogue(const KqmParams &p, uint32_t u, uin
 // past the end -> the surplus loads (non-temporal, so L2 not L1 hits) delay the short kernels (622 tok/s).
 // NS > 0: no workgroup has more than NS steps — all of them are issued before the prologue and consumed
 // in a straight line (the common case for the per-block matrices of a 3B model: 1-4 steps per wave).
-template <int MODE, int BPW, bool NORM, int NS>
-__global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_q4t(const KqmParams p)
+template <int QT, int MODE, int BPW, bool NORM, int NS>
+__global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_kqt(const KqmParams p)
 {
+    using Regs = typename std::conditional<QT == NFAI_Q4_K_T16, Q4T, Q6T>::type;
     constexpr int R = MODE == GEMV_GATEUP ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
@@ -213,16 +258,17 @@ __global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_q4t(const KqmPara
     if (p.UB & 0x100u) __builtin_amdgcn_s_barrier();
     // ---- weights of the first steps
     constexpr int NBUF = NS > 0 ? NS : 2;
-    Q4T buf[NBUF];
+    Regs buf[NBUF];
     uint32_t ist = 0;
-    auto issue = [&](Q4T &buf) {
+    auto issue = [&](Regs &buf) {
         const uint32_t is = min(ist, nsteps - 1);  // past the end: the wave's own last step again
         const uint32_t ui = is / (R * BPW), tt = (is / BPW) % R, bi = is % BPW;
         const uint32_t u = blockIdx.x + ui * gridDim.x;
         const uint32_t blk = min(wid * BPW + bi, p.NB - 1);
         uint32_t seg, tile;
         kqm_unit<MODE>(p, u, tt, seg, tile);
-        buf = q4t_load(p, seg, tile, blk, lane);
+        if constexpr (QT == NFAI_Q4_K_T16) buf = q4t_load(p, seg, tile, blk, lane);
+        else buf = q6t_load(p, seg, tile, blk, lane);
         ++ist;
     };
 #pragma unroll
@@ -282,14 +328,25 @@ __global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_q4t(const KqmPara
                 d2 |= (uint32_t)(b2 & 0xFF) << (8 * e);
                 sx += (float)xi;
             }
-            // element k = blk*256 + sb*32 + hf*16 + j: A fragment [blk][n][hf][G][digit][16 bytes], sb = 2G + n
-            const uint32_t blk = k >> 8, sb = (k >> 5) & 7, hf = (k >> 4) & 1, j = k & 15, g = sb >> 1, n = sb & 1;
-            uint8_t *frag = xa + (size_t)blk * 1024 + ((n * 2 + hf) * 4 + g) * 64 + j;
+            // A fragments [blk][slot:4][G][digit][16 bytes]; a lane reads slot s at +256*s from its (G, digit) base.
+            //   Q4_K: k = blk*256 + (2G+n)*32 + hf*16 + j, slot = 2n + hf, sums per sub-block of 32 -> [blk][G][n]
+            //   Q6_K: k = blk*256 + n*128 + qd*32 + lh*16 + j, G = 2n + lh, slot = qd, sums per group of 16 -> [blk][G][qd]
+            const uint32_t blk = k >> 8, j = k & 15;
+            uint32_t g, slot, sidx;
+            if constexpr (QT == NFAI_Q4_K_T16) {
+                const uint32_t sb = (k >> 5) & 7, hf = (k >> 4) & 1;
+                g = sb >> 1; slot = (sb & 1) * 2 + hf; sidx = sb & 1;
+                sx = dpp_add8(sx);
+            } else {
+                g = ((k >> 7) & 1) * 2 + ((k >> 4) & 1); slot = (k >> 5) & 3; sidx = slot;
+                sx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0xB1, 0xF, 0xF, true));
+                sx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0x4E, 0xF, 0xF, true));
+            }
+            uint8_t *frag = xa + (size_t)blk * 1024 + (slot * 4 + g) * 64 + j;
             *reinterpret_cast<uint32_t *>(frag) = d0;
             *reinterpret_cast<uint32_t *>(frag + 16) = d1;
             *reinterpret_cast<uint32_t *>(frag + 32) = d2;
-            sx = dpp_add8(sx);
-            if ((lane & 7) == 0) sums[(blk * 4 + g) * 4 + n] = sx;
+            if ((lane & (QT == NFAI_Q4_K_T16 ? 7 : 3)) == 0) sums[(blk * 4 + g) * 4 + sidx] = sx;
         }
         __syncthreads();
     }
@@ -300,14 +357,16 @@ __global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_q4t(const KqmPara
 
     float acc = 0.f;
     uint32_t cst = 0, par = 0;
-    auto consume = [&](Q4T &buf) {
+    auto consume = [&](Regs &buf) {
         const uint32_t ui = cst / (R * BPW), tt = (cst / BPW) % R, bi = cst % BPW;
         const uint32_t bc = wid * BPW + bi;
         const bool live = bc < p.NB;
         const uint32_t blk = min(bc, p.NB - 1);
         const uint8_t *abase = a_live ? xa + (size_t)blk * 1024 + a_off : zero;
-        const f32x2 sm = *reinterpret_cast<const f32x2 *>(sums + (blk * 4 + g) * 4);
-        const float a = q4t_dot(buf, abase, sm, g);
+        const f32x4 sm = *reinterpret_cast<const f32x4 *>(sums + (blk * 4 + g) * 4);
+        float a;
+        if constexpr (QT == NFAI_Q4_K_T16) a = q4t_dot(buf, abase, f32x2{sm[0], sm[1]}, g);
+        else a = q6t_dot(buf, abase, sm, g);
         acc += live ? a : 0.f;
         ++cst;
         if (bi == BPW - 1) {
@@ -390,6 +449,55 @@ hipError_t launch_repack_q4k_t16(const void *native, void *tiled, uint64_t rows,
     return hipGetLastError();
 }
 
+// ---- Q6_K repack: native 210-byte blocks (row-major) -> T16 planes (same bytes) ------------------------
+//   plane 0  [tile][blk][piece:3][lane:64][16 B]  lane = G*16 + r, n = G>>1, lh = G&1:
+//            piece 0 = ql[64n + 16lh ..+16), piece 1 = ql[64n + 32 + 16lh ..+16), piece 2 = qh[32n + 16lh ..+16)
+//   plane 1  [tile][blk][r:16][16 B]  the 16 int8 scales      plane 2  [tile][blk][r:16] fp16 d
+__global__ void k_repack_q6k_t16(const uint8_t *src, uint8_t *dst, uint32_t n_tiles, uint32_t NB)
+{
+    const uint64_t tb = blockIdx.x;
+    const uint32_t tile = (uint32_t)(tb / NB), blk = (uint32_t)(tb % NB), t = threadIdx.x;
+    const uint64_t nblk = (uint64_t)n_tiles * 16 * NB;
+    // native blocks are only 2-byte aligned: byte copies
+    for (uint32_t e = t; e < 3072; e += blockDim.x) {
+        const uint32_t piece = e >> 10, ln = (e >> 4) & 63, b = e & 15, G = ln >> 4, r = ln & 15, n = G >> 1, lh = G & 1;
+        const uint8_t *s = src + ((uint64_t)(tile * 16 + r) * NB + blk) * 210;
+        const uint32_t off = piece == 0 ? 64 * n + 16 * lh : (piece == 1 ? 64 * n + 32 + 16 * lh : 128 + 32 * n + 16 * lh);
+        dst[tb * 3072 + e] = s[off + b];
+    }
+    for (uint32_t e = t; e < 256; e += blockDim.x) {
+        const uint32_t r = e >> 4, b = e & 15;
+        dst[nblk * 192 + tb * 256 + e] = src[((uint64_t)(tile * 16 + r) * NB + blk) * 210 + 192 + b];
+    }
+    if (t < 32) dst[nblk * 208 + tb * 32 + t] = src[((uint64_t)(tile * 16 + (t >> 1)) * NB + blk) * 210 + 208 + (t & 1)];
+}
+
+hipError_t launch_repack_q6k_t16(const void *native, void *tiled, uint64_t rows, uint64_t cols, hipStream_t s)
+{
+    if (rows == 0) return hipSuccess;
+    if (rows % 16 || cols % 256) return hipErrorInvalidValue;
+    const uint64_t nb = cols / 256, grid = rows / 16 * nb;
+    if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    k_repack_q6k_t16<<<(uint32_t)grid, 256, 0, s>>>(static_cast<const uint8_t *>(native), static_cast<uint8_t *>(tiled), (uint32_t)(rows / 16),
+                                                    (uint32_t)nb);
+    return hipGetLastError();
+}
+
+__global__ void k_embed_q6t(const uint8_t *table, uint64_t n_rows, const uint32_t *tok, float *y, uint32_t E)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= E) return;
+    const uint32_t NB = E / 256, blk = k >> 8, kk = k & 255, n = kk >> 7, qd = (kk >> 5) & 3, l = kk & 31, lh = l >> 4, b = l & 15;
+    const uint64_t row = tok[0], tile = row >> 4, r = row & 15, tb = tile * NB + blk, nblk = n_rows * NB;
+    const uint32_t ln = (n * 2 + lh) * 16 + (uint32_t)r;
+    const uint8_t ql = table[tb * 3072 + (qd & 1) * 1024 + ln * 16 + b];
+    const uint8_t qh = table[tb * 3072 + 2048 + ln * 16 + b];
+    const int8_t sc = (int8_t)table[nblk * 192 + tb * 256 + r * 16 + 8 * n + lh + 2 * qd];
+    const float d = (float)reinterpret_cast<const _Float16 *>(table + nblk * 208 + tb * 32)[r];
+    const int q = (int)(((qd >= 2) ? (ql >> 4) : (ql & 0xF)) | (((qh >> (2 * qd)) & 3) << 4)) - 32;
+    y[k] = d * (float)sc * (float)q;
+}
+
 // ---- one row of a T16 table -> fp32 (embedding gather) ----------------------------------------------------
 __global__ void k_embed_q4t(const uint8_t *table, uint64_t n_rows, const uint32_t *tok, float *y, uint32_t E)
 {
@@ -410,13 +518,15 @@ __global__ void k_embed_q4t(const uint8_t *table, uint64_t n_rows, const uint32_
 
 hipError_t launch_embed_kqt(const void *table, int type, uint64_t n_rows, const uint32_t *tok, float *y, uint32_t E, hipStream_t s)
 {
-    if (E % 256 || n_rows % 16 || type != NFAI_Q4_K_T16) return hipErrorInvalidValue;
-    k_embed_q4t<<<(E + 255) / 256, 256, 0, s>>>(static_cast<const uint8_t *>(table), n_rows, tok, y, E);
+    if (E % 256 || n_rows % 16) return hipErrorInvalidValue;
+    if (type == NFAI_Q4_K_T16) k_embed_q4t<<<(E + 255) / 256, 256, 0, s>>>(static_cast<const uint8_t *>(table), n_rows, tok, y, E);
+    else if (type == NFAI_Q6_K_T16) k_embed_q6t<<<(E + 255) / 256, 256, 0, s>>>(static_cast<const uint8_t *>(table), n_rows, tok, y, E);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
 // ---- dispatch ------------------------------------------------------------------------------------------
-template <int MODE, int BPW>
+template <int QT, int MODE, int BPW>
 static hipError_t q4t_launch(const KqmParams &p, int ns, uint32_t grid, uint32_t block, size_t lds, hipStream_t s)
 {
     auto go = [&](auto kern) {
@@ -431,14 +541,13 @@ static hipError_t q4t_launch(const KqmParams &p, int ns, uint32_t grid, uint32_t
     };
     const bool norm = p.gamma != nullptr;
     switch (ns) {
-        case 1: return norm ? go(k_gemv_q4t<MODE, BPW, true, 1>) : go(k_gemv_q4t<MODE, BPW, false, 1>);
-        case 2: return norm ? go(k_gemv_q4t<MODE, BPW, true, 2>) : go(k_gemv_q4t<MODE, BPW, false, 2>);
-        case 4: return norm ? go(k_gemv_q4t<MODE, BPW, true, 4>) : go(k_gemv_q4t<MODE, BPW, false, 4>);
+        case 1: return norm ? go(k_gemv_kqt<QT, MODE, BPW, true, 1>) : go(k_gemv_kqt<QT, MODE, BPW, false, 1>);
+        case 2: return norm ? go(k_gemv_kqt<QT, MODE, BPW, true, 2>) : go(k_gemv_kqt<QT, MODE, BPW, false, 2>);
     }
-    return norm ? go(k_gemv_q4t<MODE, BPW, true, 0>) : go(k_gemv_q4t<MODE, BPW, false, 0>);
+    return norm ? go(k_gemv_kqt<QT, MODE, BPW, true, 0>) : go(k_gemv_kqt<QT, MODE, BPW, false, 0>);
 }
 
-template <int MODE>
+template <int QT, int MODE>
 static hipError_t q4t_bpw(const KqmParams &p, int bpw, uint32_t grid, uint32_t block, size_t lds, hipStream_t s)
 {
     // steps of the busiest workgroup; all-upfront variants exist for 1, 2 and (<= 12 waves) 4 steps
@@ -449,16 +558,15 @@ static hipError_t q4t_bpw(const KqmParams &p, int bpw, uint32_t grid, uint32_t b
     if (env_ns) {
         if (max_steps == 1) ns = 1;
         else if (max_steps == 2) ns = 2;
-        else if (env_ns >= 2 && max_steps <= 4 && block <= 768) ns = 4;  // measured slower than ping-pong (compute no longer overlaps the stream)
     }
-    if (bpw == 1) return q4t_launch<MODE, 1>(p, ns, grid, block, lds, s);
-    if (bpw == 2) return q4t_launch<MODE, 2>(p, ns, grid, block, lds, s);
-    return q4t_launch<MODE, 4>(p, ns, grid, block, lds, s);
+    if (bpw == 1) return q4t_launch<QT, MODE, 1>(p, ns, grid, block, lds, s);
+    if (bpw == 2) return q4t_launch<QT, MODE, 2>(p, ns, grid, block, lds, s);
+    return q4t_launch<QT, MODE, 4>(p, ns, grid, block, lds, s);
 }
 
 hipError_t launch_gemv_kqm(const GemvArgs &a, hipStream_t s)
 {
-    if (a.w_type != NFAI_Q4_K_T16) return hipErrorInvalidValue;
+    if (a.w_type != NFAI_Q4_K_T16 && a.w_type != NFAI_Q6_K_T16) return hipErrorInvalidValue;
     if (a.K == 0 || a.K % 256 != 0 || a.K > 16384) return hipErrorInvalidValue;
     KqmParams p{};
     uint32_t total_tiles = 0;
@@ -497,11 +605,20 @@ hipError_t launch_gemv_kqm(const GemvArgs &a, hipStream_t s)
     const size_t lds = (size_t)nw * bpw * 1024 + (size_t)nw * bpw * 64 + 1024 + (size_t)2 * p.UB * R * nw * 256 + 128;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (env_xb) p.UB |= 0x100u;  // experiment flag, see the kernel
-    switch (a.mode) {
-        case GEMV_PLAIN: return q4t_bpw<GEMV_PLAIN>(p, bpw, grid, nw * 64, lds, s);
-        case GEMV_RESIDUAL: return q4t_bpw<GEMV_RESIDUAL>(p, bpw, grid, nw * 64, lds, s);
-        case GEMV_QKV_ROPE: return q4t_bpw<GEMV_QKV_ROPE>(p, bpw, grid, nw * 64, lds, s);
-        case GEMV_GATEUP: return q4t_bpw<GEMV_GATEUP>(p, bpw, grid, nw * 64, lds, s);
+    if (a.w_type == NFAI_Q4_K_T16) {
+        switch (a.mode) {
+            case GEMV_PLAIN: return q4t_bpw<NFAI_Q4_K_T16, GEMV_PLAIN>(p, bpw, grid, nw * 64, lds, s);
+            case GEMV_RESIDUAL: return q4t_bpw<NFAI_Q4_K_T16, GEMV_RESIDUAL>(p, bpw, grid, nw * 64, lds, s);
+            case GEMV_QKV_ROPE: return q4t_bpw<NFAI_Q4_K_T16, GEMV_QKV_ROPE>(p, bpw, grid, nw * 64, lds, s);
+            case GEMV_GATEUP: return q4t_bpw<NFAI_Q4_K_T16, GEMV_GATEUP>(p, bpw, grid, nw * 64, lds, s);
+        }
+    } else {
+        switch (a.mode) {
+            case GEMV_PLAIN: return q4t_bpw<NFAI_Q6_K_T16, GEMV_PLAIN>(p, bpw, grid, nw * 64, lds, s);
+            case GEMV_RESIDUAL: return q4t_bpw<NFAI_Q6_K_T16, GEMV_RESIDUAL>(p, bpw, grid, nw * 64, lds, s);
+            case GEMV_QKV_ROPE: return q4t_bpw<NFAI_Q6_K_T16, GEMV_QKV_ROPE>(p, bpw, grid, nw * 64, lds, s);
+            case GEMV_GATEUP: return q4t_bpw<NFAI_Q6_K_T16, GEMV_GATEUP>(p, bpw, grid, nw * 64, lds, s);
+        }
     }
     return hipErrorInvalidValue;
 }

@@ -624,7 +624,7 @@ static int set_tensor_impl(Model *m, const char *name, int type, uint64_t rows, 
                              (unsigned long long)cols);
     if (t->owned && t->ptr) { HIP_TRY(hipFree(t->ptr)); }
     t->type = type; t->rows = rows; t->cols = cols; t->bytes = rb * rows;
-    const bool q4_t16 = type == NFAI_Q4_K && rows > 0 && rows % 16 == 0;
+    const bool q4_t16 = type == NFAI_Q4_K && rows > 0 && rows % 16 == 0, q6_t16 = type == NFAI_Q6_K && rows > 0 && rows % 16 == 0;
     if (type == NFAI_Q6_K || q4_t16) {
         // native blocks (host or device) -> owned repacked copy: Q6_K planes (common.h), Q4_K T16 tiles (kernels_gemv_kqm.hip)
         void *native = dev;
@@ -636,9 +636,11 @@ static int set_tensor_impl(Model *m, const char *name, int type, uint64_t rows, 
         DALLOC(t->ptr, t->bytes);
         t->owned = true;
         hipError_t e = q4_t16 ? launch_repack_q4k_t16(native, t->ptr, rows, cols, m->ctx->stream)
+                     : q6_t16 ? launch_repack_q6k_t16(native, t->ptr, rows, cols, m->ctx->stream)
                               : launch_repack_q6k(native, t->ptr, rows * cols / 256, m->ctx->stream);
         if (e != hipSuccess) return fail(NFAI_ERR_HIP, "set_tensor(%s): K-quant repack failed: %s", name, hipGetErrorString(e));
         if (q4_t16) t->type = NFAI_Q4_K_T16;
+        if (q6_t16) t->type = NFAI_Q6_K_T16;
         HIP_TRY(hipStreamSynchronize(m->ctx->stream));
         if (!dev) HIP_TRY(hipFree(native));
     } else if (dev) {
