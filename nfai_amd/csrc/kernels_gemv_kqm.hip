@@ -187,15 +187,37 @@ __device__ __forceinline__ void kqm_kv_store(void *base, int f16, uint64_t idx, 
     else reinterpret_cast<float *>(base)[idx] = v;
 }
 
+// What the epilogue of unit u reads besides the dot products; loaded unconditionally (clamped) so that the
+// first round's copy can be fetched at kernel start, a microsecond of latency off the tail of the short kernels.
+struct KqmPre { float res; f32x2 cs; uint32_t pos; };
+
+template <int MODE>
+__device__ __forceinline__ KqmPre kqm_preload(const KqmParams &p, uint32_t u, uint32_t lane)
+{
+    KqmPre q;
+    q.res = 0.f; q.cs = f32x2{1.f, 0.f}; q.pos = 0;
+    const uint32_t r = lane & 15;
+    if constexpr (MODE == GEMV_RESIDUAL) {
+        q.res = *((const GLOBAL_AS float *)p.res + (u * 16 + r));
+    } else if constexpr (MODE == GEMV_QKV_ROPE) {
+        uint32_t seg, tile;
+        kqm_unit<MODE>(p, u, 0, seg, tile);
+        const uint32_t de = ((tile * 16 + r) % p.D) & ~1u;
+        q.cs = *reinterpret_cast<const GLOBAL_AS f32x2 *>((const GLOBAL_AS float *)p.rope_cs + min(de, p.rope_dims - 2));
+        q.pos = *((const GLOBAL_AS uint32_t *)p.pos);
+    }
+    return q;
+}
+
 // lanes 0..15 hold the 16 rows of the unit (a0; a1 = up row for GATEUP)
 template <int MODE>
-__device__ __forceinline__ void kqm_epilogue(const KqmParams &p, uint32_t u, uint32_t lane, float a0, float a1)
+__device__ __forceinline__ void kqm_epilogue(const KqmParams &p, uint32_t u, uint32_t lane, float a0, float a1, const KqmPre &pre)
 {
     const uint32_t r = lane & 15;
     if constexpr (MODE == GEMV_PLAIN) {
         if (lane < 16) p.y[u * 16 + r] = a0;
     } else if constexpr (MODE == GEMV_RESIDUAL) {
-        if (lane < 16) p.y[u * 16 + r] = p.res[u * 16 + r] + a0;
+        if (lane < 16) p.y[u * 16 + r] = pre.res + a0;
     } else if constexpr (MODE == GEMV_GATEUP) {
         if (lane < 16) p.y[u * 16 + r] = a1 * silu_ref(a0);
     } else {
@@ -206,20 +228,16 @@ __device__ __forceinline__ void kqm_epilogue(const KqmParams &p, uint32_t u, uin
         float o = a0;
         const uint32_t de = dd & ~1u;  // the even element of the rotated pair
         if (seg < 2 && de < p.rope_dims) {
-            const float c = p.rope_cs[de], sn = p.rope_cs[de + 1];
+            const float c = pre.cs[0], sn = pre.cs[1];
             o = (dd & 1) ? (sn * other + c * a0) : (c * a0 - sn * other);
         }
         if (lane < 16) {
             if (seg == 0) p.y[row] = o;
-            else kqm_kv_store(seg == 1 ? p.kc : p.vc, p.kv_f16, (uint64_t)p.pos[0] * p.kv_pos_stride + (uint64_t)head * p.kv_head_stride + dd, o);
+            else kqm_kv_store(seg == 1 ? p.kc : p.vc, p.kv_f16, (uint64_t)pre.pos * p.kv_pos_stride + (uint64_t)head * p.kv_head_stride + dd, o);
         }
     }
 }
 
-// Two steps in flight per wave (ping-pong).  Measured alternatives, both slower on Llama-3.2-3B Q4_K_M
-// (714 tok/s with this shape): four buffers with conditional issues in the tail -> hipcc falls back to
-// s_waitcnt vmcnt(0) before the first consume (673 tok/s); four buffers with unconditional, clamped issues
-// past the end -> the surplus loads (non-temporal, so L2 not L1 hits) delay the short kernels (622 tok/s).
 // NS > 0: no workgroup has more than NS steps — all of them are issued before the prologue and consumed
 // in a straight line (the common case for the per-block matrices of a 3B model: 1-4 steps per wave).
 template <int QT, int MODE, int BPW, bool NORM, int NS>
@@ -256,6 +274,7 @@ __global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_kqt(const KqmPara
     // weights behind them (the pipeline is shared in order: a late wave's x would otherwise wait behind the
     // early waves' kilobytes of weights, and the prologue needs the x of ALL waves).  s_barrier only: no waitcnt.
     if (p.UB & 0x100u) __builtin_amdgcn_s_barrier();
+    const KqmPre pre0 = kqm_preload<MODE>(p, min(blockIdx.x + wid * gridDim.x, p.NU - 1), lane);  // epilogue inputs of round 0
     // ---- weights of the first steps
     constexpr int NBUF = NS > 0 ? NS : 2;
     Regs buf[NBUF];
@@ -377,6 +396,7 @@ __global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_kqt(const KqmPara
                 __syncthreads();
                 if (wid <= slot) {  // wave q finishes unit q of this round
                     const uint32_t uq = blockIdx.x + (ui - slot + wid) * gridDim.x;
+                    const KqmPre pre = ui == slot ? pre0 : kqm_preload<MODE>(p, uq, lane);
                     float af[R];
 #pragma unroll
                     for (int t2 = 0; t2 < R; t2++) {
@@ -387,7 +407,7 @@ __global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_kqt(const KqmPara
                         s += __shfl_xor(s, 32);
                         af[t2] = s * inv_scale;
                     }
-                    kqm_epilogue<MODE>(p, uq, lane, af[0], af[R - 1]);
+                    kqm_epilogue<MODE>(p, uq, lane, af[0], af[R - 1], pre);
                 }
                 par ^= 1;
             }
