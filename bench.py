@@ -252,7 +252,7 @@ def run_single(args):
                    "graph": not args.no_graph},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "kernel": ("k_gemv<F16,GATEUP>" if args.quant == "f16" else "k_gemv_kq<Q4_K,GATEUP>") + " (RMSNorm + Wgate/Wup GEMV + SiLU*up)",
+                     "kernel": ("k_gemv<F16,GATEUP>" if args.quant == "f16" else "k_gemv_kqt<Q4_K_T16,GATEUP> int8-MFMA") + " (RMSNorm + Wgate/Wup GEMV + SiLU*up)",
                      "bytes_per_launch": dom_bytes, "us_per_launch": gu_ms * 1e3},
         "token_hbm_gbps": b_tok / (ms_per_step * 1e-3) / 1e9,
         "token_hbm_frac_of_peak": b_tok / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
