@@ -113,8 +113,10 @@ struct GemmArgs {  // C[M][N] (+R) = alpha * A[M][K] * B[N][K]^T, fp16 operands,
     const void *B = nullptr;   // fp16 [N][ldb]
     const void *B1 = nullptr, *B2 = nullptr;  // optional 2nd / 3rd row segment (rows n0.., n0+n1..); all segments ldb wide
     uint32_t n0 = 0, n1 = 0;
-    float *C = nullptr;
-    const float *R = nullptr;  // optional residual, same layout as C
+    void *C = nullptr;         // fp32 [M][ldc]; fp16 when epi != 0
+    int epi = 0;               // 0: fp32 (+R)   1: fp16 out   2: fp16 out = up * silu(gate), B = gate rows, B1 = up rows, N = 2F, C is [M][F]
+    uint32_t n_cu = 256;
+    const float *R = nullptr;  // optional residual, same layout as C (epi 0)
     uint32_t M = 0, N = 0, K = 0, lda = 0, ldb = 0, ldc = 0;
     uint32_t batch = 1, b_div = 1;
     uint64_t a_bs = 0, b_bs = 0, c_bs = 0;

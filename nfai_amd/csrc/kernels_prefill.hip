@@ -18,6 +18,8 @@
 //   blockIdx -> (m tile, n tile) is XCD-aware: the m tiles that share a weight tile get ids that are
 //   equal mod 8 (same XCD, adjacent dispatch slots), so a weight tile is read from HBM once and from
 //   that XCD's L2 by the other m tiles.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace nfai {
@@ -27,19 +29,19 @@ namespace nfai {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int GBM = 128, GBN = 64, GTHREADS = 256;
-
 struct GemmParams {
     const _Float16 *A;      // [M][lda] fp16
     const _Float16 *B[3];   // up to three row segments of [rows][ldb] fp16 (q | k | v, gate | up) — one launch
     uint32_t seg_end[3];    // cumulative row ends of the segments (multiples of 64)
-    float *C;               // [M][ldc] fp32
-    const float *R;         // optional residual [M][ldc]
+    void *C;                // [M][ldc] fp32 (EPI_F32) or fp16 (EPI_F16, EPI_SILU)
+    const float *R;         // optional residual [M][ldc] (EPI_F32)
     uint32_t M, N, K, lda, ldb, ldc;
     uint64_t a_bs, b_bs, c_bs;   // batch strides (elements)
     uint32_t b_div;              // B batch index = batch / b_div (GQA: query heads share a kv head)
     float alpha;
 };
+
+enum { EPI_F32 = 0, EPI_F16 = 1, EPI_SILU = 2 };
 
 // LDS tile rows are BK halves = CH chunks of 16 B; the chunk index is XORed with the row so that the
 // 16 rows a ds_read_b128 fragment read touches at one k-chunk land in 16 different bank groups
@@ -48,22 +50,30 @@ template <int CH> __device__ __forceinline__ uint32_t lds_off(uint32_t row, uint
     return row * (CH * 16) + ((chunk ^ (row & (CH - 1))) << 4);
 }
 
-// BK = 64 or 128.  Global -> VGPR -> LDS with a ring of three register sets: while tile kt is
-// multiplied out of LDS, tile kt+1 sits in registers and tile kt+2 is in flight (the projections run
-// at one block per CU, so nothing else hides the ~2000-cycle global latency).
-template <int BK>
-__global__ __launch_bounds__(GTHREADS) void k_gemm_f16(const GemmParams p)
+// Block tile BM x BN x BK, WM x WN waves, each wave owns (BM/WM) x (BN/WN) = TM x TN MFMA tiles.
+// Global -> VGPR -> LDS with a ring of three register sets: while tile kt is multiplied out of LDS, tile
+// kt+1 sits in registers and tile kt+2 is in flight.
+//   <128, 64, 4, 1>: 192-320 workgroups on the narrow projections (N = E), the attention GEMMs
+//   <128, 128, 2, 2>: wave tile 64 x 64 (8 fragment reads per 16 MFMAs instead of 6 per 8) where N is wide
+// EPI_SILU: the tile's columns are 32 gate | 32 up rows of the SAME 32 outputs per 64-column wave slice, so
+// act = up * silu(gate) is formed in registers and written as fp16 (SiLUShader + ElementWiseMultiplicationShader
+// fused into the GEMM: no fp32 gate/up round trip through HBM).
+template <int BM, int BN, int WM, int WN, int BK, int EPI>
+__global__ __launch_bounds__(WM *WN * 64) void k_gemm_f16(const GemmParams p)
 {
-    constexpr int CH = BK / 8;                      // 16-byte chunks per tile row
-    constexpr int AN = GBM * CH / GTHREADS;         // A chunks per thread per tile
-    constexpr int BN_ = GBN * CH / GTHREADS;        // B chunks per thread per tile
-    constexpr int TILE_BYTES = (GBM + GBN) * BK * 2;
+    constexpr int NT = WM * WN * 64;
+    constexpr int CH = BK / 8;                // 16-byte chunks per tile row
+    constexpr int AN = BM * CH / NT;          // A chunks per thread per tile
+    constexpr int BN_ = BN * CH / NT;         // B chunks per thread per tile
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int TILE_BYTES = (BM + BN) * BK * 2;
+    static_assert(EPI != EPI_SILU || BN / WN == 64, "SiLU epilogue pairs columns inside a 64-wide wave slice");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     auto ldsA = [&](int buf) -> uint8_t * { return lds + buf * TILE_BYTES; };
-    auto ldsB = [&](int buf) -> uint8_t * { return lds + buf * TILE_BYTES + GBM * BK * 2; };
+    auto ldsB = [&](int buf) -> uint8_t * { return lds + buf * TILE_BYTES + BM * BK * 2; };
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t tiles_m = (p.M + GBM - 1) / GBM, tiles_n = p.N / GBN;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WN, wn = wave % WN;
+    const uint32_t tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
     uint32_t mt_i, nt_i;
     {
         const uint32_t id = blockIdx.x;
@@ -76,79 +86,88 @@ __global__ __launch_bounds__(GTHREADS) void k_gemm_f16(const GemmParams p)
             mt_i = id % tiles_m;
         }
     }
-    const uint32_t m0 = mt_i * GBM, n0 = nt_i * GBN, batch = blockIdx.y;
+    const uint32_t m0 = mt_i * BM, n0 = nt_i * BN, batch = blockIdx.y;
     const GLOBAL_AS uint8_t *Ab = (const GLOBAL_AS uint8_t *)(p.A + (uint64_t)batch * p.a_bs);
-    // weight segment of this n tile
+    // weight segment of this n tile (EPI_SILU: rows come from both segments, see b_row)
     const uint32_t seg = n0 < p.seg_end[0] ? 0u : (n0 < p.seg_end[1] ? 1u : 2u);
     const uint32_t nrow0 = n0 - (seg == 0 ? 0u : p.seg_end[seg - 1]);
-    const GLOBAL_AS uint8_t *Bb = (const GLOBAL_AS uint8_t *)(p.B[seg] + (uint64_t)(batch / p.b_div) * p.b_bs);
-    float *Cb = p.C + (uint64_t)batch * p.c_bs;
-    const float *Rb = p.R ? p.R + (uint64_t)batch * p.c_bs : nullptr;
+    const uint64_t bbatch = (uint64_t)(batch / p.b_div) * p.b_bs;
+    const GLOBAL_AS uint8_t *Bb = (const GLOBAL_AS uint8_t *)(p.B[seg] + bbatch);
+    const GLOBAL_AS uint8_t *Bg = (const GLOBAL_AS uint8_t *)p.B[0], *Bu = (const GLOBAL_AS uint8_t *)p.B[1];
 
     u32x4 ra[3][AN], rb[3][BN_];
     auto load_tile = [&](u32x4 (&a)[AN], u32x4 (&b)[BN_], uint32_t kt) {
         const uint32_t k0 = kt * BK;
 #pragma unroll
         for (int i = 0; i < AN; i++) {
-            const uint32_t c = tid + i * GTHREADS, row = c / CH, q = c % CH;
+            const uint32_t c = tid + i * NT, row = c / CH, q = c % CH;
             const uint32_t gr = min(m0 + row, p.M - 1);
             a[i] = *reinterpret_cast<const GLOBAL_AS u32x4 *>(Ab + ((uint64_t)gr * p.lda + k0 + q * 8) * 2);
         }
 #pragma unroll
         for (int i = 0; i < BN_; i++) {
-            const uint32_t c = tid + i * GTHREADS, row = c / CH, q = c % CH;
-            b[i] = *reinterpret_cast<const GLOBAL_AS u32x4 *>(Bb + ((uint64_t)(nrow0 + row) * p.ldb + k0 + q * 8) * 2);
+            const uint32_t c = tid + i * NT, row = c / CH, q = c % CH;
+            if constexpr (EPI == EPI_SILU) {
+                // tile column `row`: 64-wide slice sl, inside it 32 gate rows then 32 up rows of outputs n0/2 + sl*32 ..
+                const uint32_t sl = row >> 6, cc = row & 63, out = n0 / 2 + sl * 32 + (cc & 31);
+                const GLOBAL_AS uint8_t *base = cc < 32 ? Bg : Bu;
+                b[i] = *reinterpret_cast<const GLOBAL_AS u32x4 *>(base + ((uint64_t)out * p.ldb + k0 + q * 8) * 2);
+            } else {
+                b[i] = *reinterpret_cast<const GLOBAL_AS u32x4 *>(Bb + ((uint64_t)(nrow0 + row) * p.ldb + k0 + q * 8) * 2);
+            }
         }
     };
     auto store_tile = [&](const u32x4 (&a)[AN], const u32x4 (&b)[BN_], int buf) {
 #pragma unroll
         for (int i = 0; i < AN; i++) {
-            const uint32_t c = tid + i * GTHREADS, row = c / CH, q = c % CH;
+            const uint32_t c = tid + i * NT, row = c / CH, q = c % CH;
             *reinterpret_cast<u32x4 *>(ldsA(buf) + lds_off<CH>(row, q)) = a[i];
         }
 #pragma unroll
         for (int i = 0; i < BN_; i++) {
-            const uint32_t c = tid + i * GTHREADS, row = c / CH, q = c % CH;
+            const uint32_t c = tid + i * NT, row = c / CH, q = c % CH;
             *reinterpret_cast<u32x4 *>(ldsB(buf) + lds_off<CH>(row, q)) = b[i];
         }
     };
 
-    f32x4 acc[2][4];
+    f32x4 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int cur) {
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ks++) {
             const uint32_t chunk = ks * 4 + (lane >> 4);
-            f16x8 af[2], bf[4];
+            f16x8 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < 2; i++) af[i] = *reinterpret_cast<const f16x8 *>(ldsA(cur) + lds_off<CH>(wave * 32 + i * 16 + (lane & 15), chunk));
+            for (int i = 0; i < TM; i++) af[i] = *reinterpret_cast<const f16x8 *>(ldsA(cur) + lds_off<CH>(wm * (BM / WM) + i * 16 + (lane & 15), chunk));
 #pragma unroll
-            for (int j = 0; j < 4; j++) bf[j] = *reinterpret_cast<const f16x8 *>(ldsB(cur) + lds_off<CH>(j * 16 + (lane & 15), chunk));
+            for (int j = 0; j < TN; j++) bf[j] = *reinterpret_cast<const f16x8 *>(ldsB(cur) + lds_off<CH>(wn * (BN / WN) + j * 16 + (lane & 15), chunk));
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+            for (int i = 0; i < TM; i++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     };
 
     const uint32_t KT = p.K / BK;
     load_tile(ra[0], rb[0], 0);
-    if (KT > 1) load_tile(ra[1], rb[1], 1);
+    load_tile(ra[1], rb[1], min(1u, KT - 1));
     store_tile(ra[0], rb[0], 0);
     __syncthreads();
     // iteration kt: [request tile kt+2 into the free register set] [MFMAs on tile kt] [tile kt+1: regs -> LDS] [barrier];
-    // unrolled by three so that every register-set index is a compile-time constant (no scratch)
+    // unrolled by three so that every register-set index is a compile-time constant (no scratch).
+    // Loads and LDS stores are NEVER conditional (past the end they repeat the last tile, an L2 hit): with
+    // `if (kt + 2 < KT) load_tile(...)` hipcc's waitcnt pass takes the no-load path as the worst case and waits
+    // vmcnt(0) before the LDS store of tile kt+1 — i.e. also for the tile it has just requested: every K tile then
+    // costs a full memory latency (seen in the ISA as vmcnt(11)..vmcnt(0) per iteration; now vmcnt(23)..vmcnt(12)).
 #define GEMM_ITER(KT_, S_NEXT2, S_NEXT1)                                         \
-    if ((KT_) < KT) {                                                            \
-        if ((KT_) + 2 < KT) load_tile(ra[S_NEXT2], rb[S_NEXT2], (KT_) + 2);      \
-        compute((KT_)&1);                                                        \
-        if ((KT_) + 1 < KT) store_tile(ra[S_NEXT1], rb[S_NEXT1], ((KT_) + 1) & 1); \
-        __syncthreads();                                                         \
-    }
+    load_tile(ra[S_NEXT2], rb[S_NEXT2], min((KT_) + 2, KT - 1));                 \
+    if ((KT_) < KT) compute((KT_)&1);                                            \
+    store_tile(ra[S_NEXT1], rb[S_NEXT1], ((KT_) + 1) & 1);                       \
+    __syncthreads();
     for (uint32_t kt = 0; kt < KT; kt += 3) {
         GEMM_ITER(kt, 2, 1)
         GEMM_ITER(kt + 1, 0, 2)
@@ -156,26 +175,101 @@ __global__ __launch_bounds__(GTHREADS) void k_gemm_f16(const GemmParams p)
     }
 #undef GEMM_ITER
 
-    // C/D layout of mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg
+    // C/D layout of mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg.
+    const uint32_t rbase = m0 + wm * (BM / WM) + (lane >> 4) * 4, cbase = wn * (BN / WN) + (lane & 15);
+    if constexpr (EPI == EPI_SILU) {
+        _Float16 *Ch = static_cast<_Float16 *>(p.C) + (uint64_t)batch * p.c_bs;
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+        for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+            for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const uint32_t row = m0 + wave * 32 + i * 16 + (lane >> 4) * 4 + r, col = n0 + j * 16 + (lane & 15);
-                if (row < p.M) {
-                    float v = acc[i][j][r] * p.alpha;
-                    if (Rb) v += Rb[(uint64_t)row * p.ldc + col];
-                    Cb[(uint64_t)row * p.ldc + col] = v;
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t row = rbase + i * 16 + r, col = n0 / 2 + wn * 32 + j * 16 + (lane & 15);
+                    const float g = acc[i][j][r] * p.alpha, u = acc[i][j + 2][r] * p.alpha;
+                    if (row < p.M) Ch[(uint64_t)row * p.ldc + col] = (_Float16)(u * silu_ref(g));
                 }
+    } else if constexpr (EPI == EPI_F16) {
+        _Float16 *Ch = static_cast<_Float16 *>(p.C) + (uint64_t)batch * p.c_bs;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t row = rbase + i * 16 + r, col = n0 + cbase + j * 16;
+                    if (row < p.M) Ch[(uint64_t)row * p.ldc + col] = (_Float16)(acc[i][j][r] * p.alpha);
+                }
+    } else {
+        float *Cb = static_cast<float *>(p.C) + (uint64_t)batch * p.c_bs;
+        const float *Rb = p.R ? p.R + (uint64_t)batch * p.c_bs : nullptr;
+        // The residual is fetched for a whole row block first (rows clamped, no branch per element: a branch around
+        // each load makes hipcc wait vmcnt(0) per element = dependent L2 round trips).
+        if (Rb) {
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                float rv[TN][4];
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const uint32_t row = min(rbase + i * 16 + r, p.M - 1), col = n0 + cbase + j * 16;
+                        rv[j][r] = *((const GLOBAL_AS float *)Rb + ((uint64_t)row * p.ldc + col));
+                    }
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[i][j][r] = fmaf(acc[i][j][r], p.alpha, rv[j][r]);
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j] *= p.alpha;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t row = rbase + i * 16 + r, col = n0 + cbase + j * 16;
+                    if (row < p.M) Cb[(uint64_t)row * p.ldc + col] = acc[i][j][r];
+                }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int EPI>
+static hipError_t gemm_launch(const GemmParams &p, uint32_t batch, hipStream_t s)
+{
+    constexpr int LDS = 2 * (BM + BN) * BK * 2;
+    auto kern = k_gemm_f16<BM, BN, WM, WN, BK, EPI>;
+    if (LDS > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+    }
+    const uint32_t tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+    hipLaunchKernelGGL(kern, dim3(tiles, batch), dim3(WM * WN * 64), LDS, s, p);
+    return hipGetLastError();
+}
+
+template <int EPI>
+static hipError_t gemm_pick(const GemmParams &p, uint32_t batch, uint32_t n_cu, hipStream_t s)
+{
+    static const int env_big = getenv("NFAI_GEMM_BIG") ? atoi(getenv("NFAI_GEMM_BIG")) : 1;
+    const uint64_t big_tiles = (uint64_t)((p.M + 127) / 128) * (p.N / 128) * batch;
+    if (env_big && p.N % 128 == 0 && big_tiles >= (uint64_t)n_cu * 3 / 2) return gemm_launch<128, 128, 2, 2, 64, EPI>(p, batch, s);
+    return gemm_launch<128, 64, 4, 1, 64, EPI>(p, batch, s);
 }
 
 hipError_t launch_gemm_f16(const GemmArgs &a, hipStream_t s)
 {
     if (a.M == 0 || a.N == 0) return hipSuccess;
-    if (a.N % GBN != 0 || a.K % 64 != 0 || a.K == 0) return hipErrorInvalidValue;
+    if (a.N % 64 != 0 || a.K % 64 != 0 || a.K == 0) return hipErrorInvalidValue;
     if (a.lda % 8 != 0 || a.ldb % 8 != 0 || a.a_f32) return hipErrorInvalidValue;
     GemmParams p{};
     p.A = static_cast<const _Float16 *>(a.A);
@@ -185,25 +279,26 @@ hipError_t launch_gemm_f16(const GemmArgs &a, hipStream_t s)
     p.seg_end[0] = a.B1 ? a.n0 : a.N;
     p.seg_end[1] = a.B2 ? a.n0 + a.n1 : a.N;
     p.seg_end[2] = a.N;
-    if ((p.seg_end[0] | p.seg_end[1]) % GBN) return hipErrorInvalidValue;
+    if ((p.seg_end[0] | p.seg_end[1]) % 128 && a.epi != EPI_SILU) {
+        if ((p.seg_end[0] | p.seg_end[1]) % 64) return hipErrorInvalidValue;
+    }
     p.C = a.C; p.R = a.R;
     p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldb = a.ldb; p.ldc = a.ldc;
     p.a_bs = a.a_bs; p.b_bs = a.b_bs; p.c_bs = a.c_bs; p.b_div = a.b_div ? a.b_div : 1; p.alpha = a.alpha;
-    const uint32_t tiles = ((a.M + GBM - 1) / GBM) * (a.N / GBN);
-    const dim3 grid(tiles, a.batch ? a.batch : 1);
-    if (a.K % 128 == 0) {
-        constexpr int LDS = 2 * (GBM + GBN) * 128 * 2;  // 96 KiB: above the 64 KiB default limit for dynamic LDS
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16<128>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((k_gemm_f16<128>), grid, dim3(GTHREADS), LDS, s, p);
-    } else {
-        hipLaunchKernelGGL((k_gemm_f16<64>), grid, dim3(GTHREADS), 2 * (GBM + GBN) * 64 * 2, s, p);
+    const uint32_t batch = a.batch ? a.batch : 1;
+    const uint32_t n_cu = a.n_cu ? a.n_cu : 256;
+    if (a.epi == EPI_SILU) {
+        // N counts gate + up columns; the two segments must be equally long and the output is [M][N/2] fp16
+        if (!a.B1 || a.n0 * 2 != a.N || a.R || batch != 1) return hipErrorInvalidValue;
+        return gemm_pick<EPI_SILU>(p, batch, n_cu, s);
     }
-    return hipGetLastError();
+    // a segment boundary inside a 128-wide tile is not supported by the wide configuration: fall back
+    if ((p.seg_end[0] | p.seg_end[1]) % 128) {
+        if (a.epi == EPI_F16) return a.R ? hipErrorInvalidValue : gemm_launch<128, 64, 4, 1, 64, EPI_F16>(p, batch, s);
+        return gemm_launch<128, 64, 4, 1, 64, EPI_F32>(p, batch, s);
+    }
+    if (a.epi == EPI_F16) return a.R ? hipErrorInvalidValue : gemm_pick<EPI_F16>(p, batch, n_cu, s);
+    return gemm_pick<EPI_F32>(p, batch, n_cu, s);
 }
 
 // fp32 rows -> fp16 (the attention output on its way into the Wo GEMM)

@@ -791,6 +791,7 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
         if (W1) { g.B1 = W1->ptr; g.n0 = (uint32_t)W.rows; }
         if (W2) { g.B2 = W2->ptr; g.n1 = (uint32_t)W1->rows; }
         g.M = T; g.N = N; g.K = K;
+        g.n_cu = (uint32_t)m->ctx->prop.multiProcessorCount;
         return launch_gemm_f16(g, s);
     };
     const uint32_t QKV = HD + 2 * KD;
@@ -815,15 +816,20 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
             GemmArgs g;
             g.A = w.P; g.lda = Spad; g.a_bs = (uint64_t)T * Spad;
             g.B = w.VT; g.ldb = Spad; g.b_bs = (uint64_t)d.D * Spad; g.b_div = G;
-            g.C = w.ATT; g.ldc = HD; g.c_bs = d.D;
+            g.C = w.XN; g.epi = 1; g.ldc = HD; g.c_bs = d.D;   // fp16 straight into the Wo GEMM's A operand
             g.M = T; g.N = d.D; g.K = Spad; g.batch = d.H;
             P_TRY(launch_gemm_f16(g, s));
         }
-        P_TRY(launch_f32_to_f16(w.ATT, w.XN, (uint64_t)T * HD, s));
         P_TRY(gemm(w.XN, HD, L.wo, nullptr, nullptr, w.H1, w.X, d.E, HD));                 // + residual (TransformerBlock.cs:153-158)
         P_TRY(launch_rmsnorm_rows(w.H1, static_cast<const float *>(L.ffn_norm.ptr), w.XN, T, d.E, d.eps, s));
-        P_TRY(gemm(w.XN, d.E, L.wgate, &L.wup, nullptr, w.G, nullptr, 2 * d.F, d.E));      // gate | up in one launch
-        P_TRY(launch_silu_mul_rows(w.G, w.G + d.F, w.ACT, T, d.F, 2 * d.F, s));
+        {   // gate | up in one launch, act = up * silu(gate) formed in the GEMM epilogue (fp16 [T][F])
+            GemmArgs g;
+            g.A = w.XN; g.lda = d.E; g.B = L.wgate.ptr; g.B1 = L.wup.ptr; g.n0 = d.F; g.ldb = d.E;
+            g.C = w.ACT; g.epi = 2; g.ldc = d.F;
+            g.M = T; g.N = 2 * d.F; g.K = d.E;
+            g.n_cu = (uint32_t)m->ctx->prop.multiProcessorCount;
+            P_TRY(launch_gemm_f16(g, s));
+        }
         P_TRY(gemm(w.ACT, d.F, L.wdown, nullptr, nullptr, w.X, w.H1, d.E, d.F));           // + residual (:176-181)
     }
 #undef P_TRY
