@@ -58,10 +58,17 @@ template <int CH> __device__ __forceinline__ uint32_t lds_off(uint32_t row, uint
 // EPI_SILU: the tile's columns are 32 gate | 32 up rows of the SAME 32 outputs per 64-column wave slice, so
 // act = up * silu(gate) is formed in registers and written as fp16 (SiLUShader + ElementWiseMultiplicationShader
 // fused into the GEMM: no fp32 gate/up round trip through HBM).
-template <int BM, int BN, int WM, int WN, int BK, int EPI>
-__global__ __launch_bounds__(WM *WN * 64) void k_gemm_f16(const GemmParams p)
+// KS > 1: KS wave groups share the tile and split every K tile's k-steps between them (twice the waves per SIMD to
+// overlap fragment reads, MFMAs and staging when only ~one workgroup fits or exists per CU); their accumulators
+// meet in LDS once, after the K loop.
+// RING = register sets of staged tiles: RING-1 K tiles of global loads are in flight per workgroup.  A workgroup's
+// stream rate is (bytes in flight) / (memory latency): with one workgroup per CU, 2 tiles x 24 KB over ~2500 cycles
+// is ~19 B/clk/CU (measured on the Wo / Wdown GEMMs of 192 workgroups), so those get RING = 5.
+template <int BM, int BN, int WM, int WN, int BK, int EPI, int KS, int RING>
+__global__ __launch_bounds__(WM *WN *KS * 64) void k_gemm_f16(const GemmParams p)
 {
-    constexpr int NT = WM * WN * 64;
+    constexpr int NT = WM * WN * KS * 64;
+    static_assert((BK / 32) % KS == 0, "k-steps of a tile must divide over the wave groups");
     constexpr int CH = BK / 8;                // 16-byte chunks per tile row
     constexpr int AN = BM * CH / NT;          // A chunks per thread per tile
     constexpr int BN_ = BN * CH / NT;         // B chunks per thread per tile
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f16(const GemmParams p)
     auto ldsA = [&](int buf) -> uint8_t * { return lds + buf * TILE_BYTES; };
     auto ldsB = [&](int buf) -> uint8_t * { return lds + buf * TILE_BYTES + BM * BK * 2; };
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WN, wn = wave % WN;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) % (WM * WN), ksg = (tid >> 6) / (WM * WN), wm = wave / WN, wn = wave % WN;
     const uint32_t tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
     uint32_t mt_i, nt_i;
     {
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f16(const GemmParams p)
     const GLOBAL_AS uint8_t *Bb = (const GLOBAL_AS uint8_t *)(p.B[seg] + bbatch);
     const GLOBAL_AS uint8_t *Bg = (const GLOBAL_AS uint8_t *)p.B[0], *Bu = (const GLOBAL_AS uint8_t *)p.B[1];
 
-    u32x4 ra[3][AN], rb[3][BN_];
+    u32x4 ra[RING][AN], rb[RING][BN_];
     auto load_tile = [&](u32x4 (&a)[AN], u32x4 (&b)[BN_], uint32_t kt) {
         const uint32_t k0 = kt * BK;
 #pragma unroll
@@ -138,7 +145,8 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f16(const GemmParams p)
 
     auto compute = [&](int cur) {
 #pragma unroll
-        for (int ks = 0; ks < BK / 32; ks++) {
+        for (int kk = 0; kk < BK / 32 / KS; kk++) {
+            const uint32_t ks = ksg * (BK / 32 / KS) + kk;
             const uint32_t chunk = ks * 4 + (lane >> 4);
             f16x8 af[TM], bf[TN];
 #pragma unroll
@@ -153,28 +161,47 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f16(const GemmParams p)
     };
 
     const uint32_t KT = p.K / BK;
-    load_tile(ra[0], rb[0], 0);
-    load_tile(ra[1], rb[1], min(1u, KT - 1));
+#pragma unroll
+    for (int r = 0; r < RING - 1; r++) load_tile(ra[r], rb[r], min((uint32_t)r, KT - 1));
     store_tile(ra[0], rb[0], 0);
     __syncthreads();
-    // iteration kt: [request tile kt+2 into the free register set] [MFMAs on tile kt] [tile kt+1: regs -> LDS] [barrier];
-    // unrolled by three so that every register-set index is a compile-time constant (no scratch).
+    // iteration kt: [request tile kt+RING-1 into the free register set] [MFMAs on tile kt] [tile kt+1: regs -> LDS]
+    // [barrier]; unrolled by RING so that every register-set index is a compile-time constant (no scratch).
     // Loads and LDS stores are NEVER conditional (past the end they repeat the last tile, an L2 hit): with
     // `if (kt + 2 < KT) load_tile(...)` hipcc's waitcnt pass takes the no-load path as the worst case and waits
-    // vmcnt(0) before the LDS store of tile kt+1 — i.e. also for the tile it has just requested: every K tile then
+    // vmcnt(0) before the LDS store of tile kt+1 — i.e. also for the tiles it has just requested: every K tile then
     // costs a full memory latency (seen in the ISA as vmcnt(11)..vmcnt(0) per iteration; now vmcnt(23)..vmcnt(12)).
-#define GEMM_ITER(KT_, S_NEXT2, S_NEXT1)                                         \
-    load_tile(ra[S_NEXT2], rb[S_NEXT2], min((KT_) + 2, KT - 1));                 \
-    if ((KT_) < KT) compute((KT_)&1);                                            \
-    store_tile(ra[S_NEXT1], rb[S_NEXT1], ((KT_) + 1) & 1);                       \
-    __syncthreads();
-    for (uint32_t kt = 0; kt < KT; kt += 3) {
-        GEMM_ITER(kt, 2, 1)
-        GEMM_ITER(kt + 1, 0, 2)
-        GEMM_ITER(kt + 2, 1, 0)
+    for (uint32_t kt0 = 0; kt0 < KT; kt0 += RING) {
+#pragma unroll
+        for (int r = 0; r < RING; r++) {
+            const uint32_t kt = kt0 + r;
+            load_tile(ra[(r + RING - 1) % RING], rb[(r + RING - 1) % RING], min(kt + RING - 1, KT - 1));
+            if (kt < KT) compute(kt & 1);
+            store_tile(ra[(r + 1) % RING], rb[(r + 1) % RING], (kt + 1) & 1);
+            __syncthreads();
+        }
     }
-#undef GEMM_ITER
 
+    if constexpr (KS > 1) {
+        // the last __syncthreads() of the loop has passed: the tile buffers are free.  Group g > 0 parks its
+        // accumulators at [g-1][wave][i][j][lane] (16 B per lane: conflict-free), group 0 adds them up.
+        f32x4 *park = reinterpret_cast<f32x4 *>(lds);
+        static_assert((KS - 1) * WM * WN * TM * TN * 64 * 16 <= 2 * TILE_BYTES, "accumulator exchange must fit the tile buffers");
+        if (ksg > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) park[((((ksg - 1) * (WM * WN) + wave) * TM + i) * TN + j) * 64 + lane] = acc[i][j];
+        }
+        __syncthreads();
+        if (ksg > 0) return;
+#pragma unroll
+        for (int g = 1; g < KS; g++)
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j] += park[((((g - 1) * (WM * WN) + wave) * TM + i) * TN + j) * 64 + lane];
+    }
     // C/D layout of mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg.
     const uint32_t rbase = m0 + wm * (BM / WM) + (lane >> 4) * 4, cbase = wn * (BN / WN) + (lane & 15);
     if constexpr (EPI == EPI_SILU) {
@@ -239,11 +266,11 @@ __global__ __launch_bounds__(WM *WN * 64) void k_gemm_f16(const GemmParams p)
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int EPI>
+template <int BM, int BN, int WM, int WN, int BK, int EPI, int KS = 1, int RING = 3>
 static hipError_t gemm_launch(const GemmParams &p, uint32_t batch, hipStream_t s)
 {
     constexpr int LDS = 2 * (BM + BN) * BK * 2;
-    auto kern = k_gemm_f16<BM, BN, WM, WN, BK, EPI>;
+    auto kern = k_gemm_f16<BM, BN, WM, WN, BK, EPI, KS, RING>;
     if (LDS > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -253,7 +280,7 @@ static hipError_t gemm_launch(const GemmParams &p, uint32_t batch, hipStream_t s
         }
     }
     const uint32_t tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles, batch), dim3(WM * WN * 64), LDS, s, p);
+    hipLaunchKernelGGL(kern, dim3(tiles, batch), dim3(WM * WN * KS * 64), LDS, s, p);
     return hipGetLastError();
 }
 
@@ -263,6 +290,16 @@ static hipError_t gemm_pick(const GemmParams &p, uint32_t batch, uint32_t n_cu, 
     static const int env_big = getenv("NFAI_GEMM_BIG") ? atoi(getenv("NFAI_GEMM_BIG")) : 1;
     const uint64_t big_tiles = (uint64_t)((p.M + 127) / 128) * (p.N / 128) * batch;
     if (env_big && p.N % 128 == 0 && big_tiles >= (uint64_t)n_cu * 3 / 2) return gemm_launch<128, 128, 2, 2, 64, EPI>(p, batch, s);
+    // at most ~one workgroup per CU: nothing else hides latency, so twice the bytes in flight and half the barriers
+    static const int env_bk = getenv("NFAI_GEMM_BK128") ? atoi(getenv("NFAI_GEMM_BK128")) : 0;  // measured: 3 % slower than BK = 64
+    const uint64_t small_tiles = (uint64_t)((p.M + 127) / 128) * (p.N / 64) * batch;
+    if (env_bk && p.K % 128 == 0 && small_tiles <= (uint64_t)n_cu * 3 / 2) return gemm_launch<128, 64, 4, 1, 128, EPI>(p, batch, s);
+    static const int env_ks = getenv("NFAI_GEMM_KS") ? atoi(getenv("NFAI_GEMM_KS")) : 0;  // measured: no gain (the limit is bytes in flight)
+    if (env_ks && small_tiles <= (uint64_t)n_cu * 3 / 2) return gemm_launch<128, 64, 4, 1, 64, EPI, 2>(p, batch, s);
+    static const int env_m64 = getenv("NFAI_GEMM_M64") ? atoi(getenv("NFAI_GEMM_M64")) : 0;  // measured: 15 % slower than 128 x 64 on 192 workgroups
+    if (env_m64 && small_tiles < n_cu && p.M > 64) return gemm_launch<64, 64, 2, 1, 64, EPI>(p, batch, s);  // fewer tiles than CUs: halve the M tile
+    static const int env_ring = getenv("NFAI_GEMM_RING") ? atoi(getenv("NFAI_GEMM_RING")) : 3;  // measured: 5 is 5 % slower
+    if (env_ring == 5 && small_tiles <= (uint64_t)n_cu * 3 / 2) return gemm_launch<128, 64, 4, 1, 64, EPI, 1, 5>(p, batch, s);
     return gemm_launch<128, 64, 4, 1, 64, EPI>(p, batch, s);
 }
 
@@ -315,7 +352,40 @@ hipError_t launch_f32_to_f16(const float *x, void *y_f16, uint64_t n, hipStream_
 }
 
 // ---- row-batched small ops ------------------------------------------------------------------------
-// RMSNormShader over T rows, output fp16 (the next GEMM's A operand).  One block per row.
+// RMSNormShader over T rows, output fp16 (the next GEMM's A operand).  One block per row; rows of up to
+// 256 * 4 * NV floats stay in registers between the two passes (16-byte loads, 8-byte fp16 stores).
+template <int NV>
+__global__ __launch_bounds__(256) void k_rmsnorm_rows_v(const float *x, const float *g, _Float16 *y, uint32_t E, float eps)
+{
+    __shared__ float red[16];
+    const GLOBAL_AS float *xr = (const GLOBAL_AS float *)x + (uint64_t)blockIdx.x * E;
+    const GLOBAL_AS float *gr = (const GLOBAL_AS float *)g;
+    _Float16 *yr = y + (uint64_t)blockIdx.x * E;
+    f32x4 v[NV], gv[NV];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const uint32_t k = (threadIdx.x + i * 256) * 4, kk = min(k, E - 4);
+        const f32x4 a = *reinterpret_cast<const GLOBAL_AS f32x4 *>(xr + kk);
+        gv[i] = *reinterpret_cast<const GLOBAL_AS f32x4 *>(gr + kk);
+        v[i] = k < E ? a : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; e++) ss = fmaf(v[i][e], v[i][e], ss);
+    }
+    ss = block_sum(ss, red);
+    const float rms = sqrtf(ss / (float)E + eps);
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const uint32_t k = (threadIdx.x + i * 256) * 4;
+        if (k < E) {
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = (_Float16)((v[i][e] / rms) * gv[i][e]);
+            *reinterpret_cast<f16x4 *>(yr + k) = o;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_rmsnorm_rows(const float *x, const float *g, _Float16 *y, uint32_t E, float eps)
 {
     __shared__ float red[16];
@@ -330,7 +400,15 @@ __global__ __launch_bounds__(256) void k_rmsnorm_rows(const float *x, const floa
 
 hipError_t launch_rmsnorm_rows(const float *x, const float *g, void *y_f16, uint32_t T, uint32_t E, float eps, hipStream_t s)
 {
-    k_rmsnorm_rows<<<T, 256, 0, s>>>(x, g, static_cast<_Float16 *>(y_f16), E, eps);
+    _Float16 *y = static_cast<_Float16 *>(y_f16);
+    if (E % 4 == 0 && E >= 4 && E <= 4096) {
+        if (E <= 1024) k_rmsnorm_rows_v<1><<<T, 256, 0, s>>>(x, g, y, E, eps);
+        else if (E <= 2048) k_rmsnorm_rows_v<2><<<T, 256, 0, s>>>(x, g, y, E, eps);
+        else if (E <= 3072) k_rmsnorm_rows_v<3><<<T, 256, 0, s>>>(x, g, y, E, eps);
+        else k_rmsnorm_rows_v<4><<<T, 256, 0, s>>>(x, g, y, E, eps);
+    } else {
+        k_rmsnorm_rows<<<T, 256, 0, s>>>(x, g, y, E, eps);
+    }
     return hipGetLastError();
 }
 
@@ -418,6 +496,54 @@ hipError_t launch_kv_to_f16(const void *kc, const void *vc, int kv_f16, uint64_t
 // causal softmax of one score row: query t (absolute position pos0 + t) attends keys 0..pos0+t.
 // scores [H][T][Spad] fp32 (unscaled dot products) -> P fp16, zero beyond the causal limit.
 // AttentionSoftmaxShader.cs:148-177 semantics (max, exp(clamp(.,-80,80)), sum, 1/sum).
+// Fast form: one wave per row, the row (Spad <= 256 * NV) in registers, wave reductions only.
+template <int NV>
+__global__ __launch_bounds__(256) void k_softmax_causal_rows_w(const float *sc, _Float16 *p, uint32_t rows, uint32_t T, uint32_t Spad,
+                                                               uint32_t pos0, float scale)
+{
+    const uint32_t rowi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (rowi >= rows) return;
+    const uint32_t t = rowi % T, n = pos0 + t + 1;
+    const GLOBAL_AS float *row = (const GLOBAL_AS float *)sc + (uint64_t)rowi * Spad;
+    _Float16 *prow = p + (uint64_t)rowi * Spad;
+    f32x4 v[NV];
+    float m = -1.0e38f;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const uint32_t k = (lane + i * 64) * 4;
+        v[i] = *reinterpret_cast<const GLOBAL_AS f32x4 *>(row + min(k, Spad - 4));
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            v[i][e] *= scale;
+            if (k + e < n) m = fmaxf(m, v[i][e]);
+        }
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const uint32_t k = (lane + i * 64) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float ex = expf(fminf(fmaxf(v[i][e] - m, -80.f), 80.f));
+            v[i][e] = k + e < n ? ex : 0.f;
+            sum += v[i][e];
+        }
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const uint32_t k = (lane + i * 64) * 4;
+        if (k < Spad) {
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = (_Float16)(v[i][e] * inv);
+            *reinterpret_cast<f16x4 *>(prow + k) = o;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_softmax_causal_rows(const float *sc, _Float16 *p, uint32_t T, uint32_t Spad, uint32_t pos0,
                                                              float scale)
 {
@@ -443,7 +569,17 @@ __global__ __launch_bounds__(256) void k_softmax_causal_rows(const float *sc, _F
 hipError_t launch_softmax_causal_rows(const float *sc, void *p_f16, uint32_t H, uint32_t T, uint32_t Spad, uint32_t pos0, float scale,
                                       hipStream_t s)
 {
-    k_softmax_causal_rows<<<H * T, 256, 0, s>>>(sc, static_cast<_Float16 *>(p_f16), T, Spad, pos0, scale);
+    _Float16 *p = static_cast<_Float16 *>(p_f16);
+    const uint32_t rows = H * T;
+    if (Spad % 4 == 0 && Spad >= 4 && Spad <= 2048) {
+        const uint32_t grid = (rows + 3) / 4;
+        if (Spad <= 256) k_softmax_causal_rows_w<1><<<grid, 256, 0, s>>>(sc, p, rows, T, Spad, pos0, scale);
+        else if (Spad <= 512) k_softmax_causal_rows_w<2><<<grid, 256, 0, s>>>(sc, p, rows, T, Spad, pos0, scale);
+        else if (Spad <= 1024) k_softmax_causal_rows_w<4><<<grid, 256, 0, s>>>(sc, p, rows, T, Spad, pos0, scale);
+        else k_softmax_causal_rows_w<8><<<grid, 256, 0, s>>>(sc, p, rows, T, Spad, pos0, scale);
+    } else {
+        k_softmax_causal_rows<<<rows, 256, 0, s>>>(sc, p, T, Spad, pos0, scale);
+    }
     return hipGetLastError();
 }
 
