@@ -180,13 +180,13 @@ def run_single(args):
     # token 0 with logits (parity side-check against the CPU baseline)
     logits0, tok = m.Step(first_token)
     m.Reset()
-    # ---- context: `context` prompt tokens.  fp16 models take the batched MFMA prefill (BASELINE config
-    #      "512-token prefill + 128-token decode"), timed separately; K-quant models (no MFMA prefill
-    #      kernel yet) fill the cache through the decode path as the reference does.  Untimed for `value`.
+    # ---- context: `context` prompt tokens through the batched MFMA prefill (BASELINE config "512-token prefill +
+    #      128-token decode"), timed separately; K-quant blocks are widened to an fp16 scratch per block and take the
+    #      same GEMMs.  --no-mfma-prefill fills the cache through the decode path as the reference does.  Untimed for `value`.
     prefill = None
     prompt = synth.make_tokens(dims, args.context, seed=99)
     prompt[0] = first_token
-    if args.quant == "f16" and not args.no_mfma_prefill:
+    if not args.no_mfma_prefill:
         m.Prefill(prompt, want_logits=False)          # warm (first-touch of the workspace)
         m.Reset()
         mgr.Synchronize()
@@ -199,7 +199,8 @@ def run_single(args):
         flops = dims.L * (per_layer + attn) + 2 * dims.V * dims.E
         prefill = {"tokens": T, "ms": pf_ms, "tokens_per_s": T / (pf_ms * 1e-3), "tflops": flops / (pf_ms * 1e-3) / 1e12,
                    "peak_tflops": 2500.0, "frac_of_mfma_peak": flops / (pf_ms * 1e-3) / 1e12 / 2500.0,
-                   "kernel": "k_gemm_f16 (mfma_f32_16x16x32_f16, 128x64x64 tiles) + batched attention GEMMs"}
+                   "kernel": "k_gemm_f16 (mfma_f32_16x16x32_f16; 128x128x64 / 128x64x64 tiles, SiLU*up and fp16 epilogues fused) + batched "
+                             "attention GEMMs" + ("" if args.quant == "f16" else "; per-block K-quant -> fp16 widening included")}
     else:
         m.SetToken(first_token)
         m.Enqueue(args.context)

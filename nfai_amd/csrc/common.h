@@ -100,6 +100,8 @@ hipError_t launch_gemv_kqm(const GemvArgs &a, hipStream_t s); // Q4_K_T16: MFMA 
 hipError_t launch_repack_q4k_t16(const void *native, void *tiled, uint64_t rows, uint64_t cols, hipStream_t s);
 hipError_t launch_repack_q6k_t16(const void *native, void *tiled, uint64_t rows, uint64_t cols, hipStream_t s);
 hipError_t launch_embed_kqt(const void *table, int type, uint64_t n_rows, const uint32_t *tok, float *y, uint32_t E, hipStream_t s);
+hipError_t launch_embed_rows_kqt(const void *table, int type, uint64_t n_rows, const uint32_t *toks, float *y, uint32_t T, uint32_t E, hipStream_t s);
+hipError_t launch_dequant_t16_f16(const void *W, int type, uint64_t rows, uint64_t cols, void *out_f16, hipStream_t s);  // T16 K-quant -> fp16 [rows][cols]
 // Q6_K super-blocks are 210 bytes (not 16-byte aligned): in HBM they live as four planes
 // ql | qh | scales | d (same bytes, naturally aligned accesses).  nblk = rows * cols / 256.
 hipError_t launch_repack_q6k(const void *native, void *planes, uint64_t nblk, hipStream_t s);

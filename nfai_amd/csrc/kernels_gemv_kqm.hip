@@ -507,6 +507,8 @@ __global__ void k_embed_q6t(const uint8_t *table, uint64_t n_rows, const uint32_
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= E) return;
+    tok += blockIdx.y;
+    y += (uint64_t)blockIdx.y * E;
     const uint32_t NB = E / 256, blk = k >> 8, kk = k & 255, n = kk >> 7, qd = (kk >> 5) & 3, l = kk & 31, lh = l >> 4, b = l & 15;
     const uint64_t row = tok[0], tile = row >> 4, r = row & 15, tb = tile * NB + blk, nblk = n_rows * NB;
     const uint32_t ln = (n * 2 + lh) * 16 + (uint32_t)r;
@@ -523,6 +525,8 @@ __global__ void k_embed_q4t(const uint8_t *table, uint64_t n_rows, const uint32_
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= E) return;
+    tok += blockIdx.y;  // row t of a batch (prefill) -> y[t][E]
+    y += (uint64_t)blockIdx.y * E;
     const uint32_t NB = E / 256, blk = k >> 8, kk = k & 255, sb = kk >> 5, l = kk & 31;
     const uint64_t row = tok[0], tile = row >> 4, r = row & 15, tb = tile * NB + blk, nblk = n_rows * NB;
     const uint8_t *hdr = table + nblk * 128 + tb * 256 + r * 16;
@@ -536,11 +540,97 @@ __global__ void k_embed_q4t(const uint8_t *table, uint64_t n_rows, const uint32_
     y[k] = d * (float)sc * qv - dmin * (float)m;
 }
 
+hipError_t launch_embed_rows_kqt(const void *table, int type, uint64_t n_rows, const uint32_t *toks, float *y, uint32_t T, uint32_t E, hipStream_t s)
+{
+    if (E % 256 || n_rows % 16 || T == 0) return hipErrorInvalidValue;
+    const dim3 grid((E + 255) / 256, T);
+    if (type == NFAI_Q4_K_T16) k_embed_q4t<<<grid, 256, 0, s>>>(static_cast<const uint8_t *>(table), n_rows, toks, y, E);
+    else if (type == NFAI_Q6_K_T16) k_embed_q6t<<<grid, 256, 0, s>>>(static_cast<const uint8_t *>(table), n_rows, toks, y, E);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 hipError_t launch_embed_kqt(const void *table, int type, uint64_t n_rows, const uint32_t *tok, float *y, uint32_t E, hipStream_t s)
 {
-    if (E % 256 || n_rows % 16) return hipErrorInvalidValue;
-    if (type == NFAI_Q4_K_T16) k_embed_q4t<<<(E + 255) / 256, 256, 0, s>>>(static_cast<const uint8_t *>(table), n_rows, tok, y, E);
-    else if (type == NFAI_Q6_K_T16) k_embed_q6t<<<(E + 255) / 256, 256, 0, s>>>(static_cast<const uint8_t *>(table), n_rows, tok, y, E);
+    return launch_embed_rows_kqt(table, type, n_rows, tok, y, 1, E, s);
+}
+
+// ---- T16 tensor -> fp16 [rows][cols] (K-quant prefill: one block's matrices are widened into a scratch buffer and
+// go through the fp16 MFMA GEMMs of kernels_prefill.hip; the decode path never dequantises to memory) -------------------
+// One wave per (tile, super-block); lane (G, r) expands the 64 weights it also owns in the GEMV.
+template <int QT>
+__global__ __launch_bounds__(256) void k_dequant_t16(const uint8_t *W, _Float16 *out, uint32_t n_tiles, uint32_t NB)
+{
+    const uint64_t tb = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tb >= (uint64_t)n_tiles * NB) return;
+    const uint32_t lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
+    const uint32_t tile = (uint32_t)(tb / NB), blk = (uint32_t)(tb % NB);
+    const uint64_t nblk = (uint64_t)n_tiles * 16 * NB;
+    _Float16 *orow = out + ((uint64_t)tile * 16 + r) * ((uint64_t)NB * 256) + (uint64_t)blk * 256;
+    if constexpr (QT == NFAI_Q4_K_T16) {
+        const u32x4 q0 = load_nt16(W + tb * 2048 + lane * 16), q1 = load_nt16(W + tb * 2048 + 1024 + lane * 16);
+        const u32x4 hdr = load_nt16(W + nblk * 128 + tb * 256 + r * 16);
+        const float d = h2f_lo(hdr[0]), dmin = h2f_hi(hdr[0]);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t sb = 2 * g + h, sh = (sb & 3) * 8;
+            const uint32_t lo8 = (hdr[1] >> sh) & 0xFFu, mid = (hdr[2] >> sh) & 0xFFu, hi8 = (hdr[3] >> sh) & 0xFFu;
+            const bool low = sb < 4;
+            const uint32_t sc = low ? (lo8 & 63u) : ((hi8 & 0xFu) | ((lo8 >> 6) << 4));
+            const uint32_t mn = low ? (mid & 63u) : ((hi8 >> 4) | ((mid >> 6) << 4));
+            const float d1 = d * (float)sc, m1 = dmin * (float)mn;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {  // 8 weights = bytes 8c .. 8c+7 of the 32-byte run
+                const u32x4 q = c < 2 ? q0 : q1;
+                const uint32_t wa = q[2 * (c & 1)], wb = q[2 * (c & 1) + 1];
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const uint32_t byte = ((e < 4 ? wa : wb) >> (8 * (e & 3))) & 0xFFu;
+                    const uint32_t nib = h ? (byte >> 4) : (byte & 0xFu);
+                    o[e] = (_Float16)(d1 * (float)nib - m1);
+                }
+                *reinterpret_cast<f16x8 *>(orow + sb * 32 + c * 8) = o;
+            }
+        }
+    } else {
+        const u32x4 qla = load_nt16(W + tb * 3072 + lane * 16), qlb = load_nt16(W + tb * 3072 + 1024 + lane * 16);
+        const u32x4 qh = load_nt16(W + tb * 3072 + 2048 + lane * 16);
+        const u32x4 scv = load_nt16(W + nblk * 192 + tb * 256 + r * 16);
+        const float d = (float)*reinterpret_cast<const _Float16 *>(W + nblk * 208 + tb * 32 + r * 2);
+        const uint32_t n = g >> 1, lh = g & 1;
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) {
+            const u32x4 ql = (qd & 1) ? qlb : qla;
+            const uint32_t si = 8 * n + lh + 2 * qd;
+            const uint32_t sw = si < 8 ? (si < 4 ? scv[0] : scv[1]) : (si < 12 ? scv[2] : scv[3]);
+            const float dsc = d * (float)(int)(int8_t)((sw >> ((si & 3) * 8)) & 0xFFu);
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const uint32_t j = c * 8 + e;
+                    const uint32_t lb = (ql[j >> 2] >> (8 * (j & 3))) & 0xFFu, hb = (qh[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                    const int q = (int)(((qd >= 2) ? (lb >> 4) : (lb & 0xFu)) | (((hb >> (2 * qd)) & 3u) << 4)) - 32;
+                    o[e] = (_Float16)(dsc * (float)q);
+                }
+                *reinterpret_cast<f16x8 *>(orow + n * 128 + qd * 32 + lh * 16 + c * 8) = o;
+            }
+        }
+    }
+}
+
+hipError_t launch_dequant_t16_f16(const void *W, int type, uint64_t rows, uint64_t cols, void *out_f16, hipStream_t s)
+{
+    if (rows == 0) return hipSuccess;
+    if (rows % 16 || cols % 256) return hipErrorInvalidValue;
+    const uint64_t n_tiles = rows / 16, nb = cols / 256, grid = (n_tiles * nb + 3) / 4;
+    if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (type == NFAI_Q4_K_T16)
+        k_dequant_t16<NFAI_Q4_K_T16><<<(uint32_t)grid, 256, 0, s>>>(static_cast<const uint8_t *>(W), static_cast<_Float16 *>(out_f16), (uint32_t)n_tiles, (uint32_t)nb);
+    else if (type == NFAI_Q6_K_T16)
+        k_dequant_t16<NFAI_Q6_K_T16><<<(uint32_t)grid, 256, 0, s>>>(static_cast<const uint8_t *>(W), static_cast<_Float16 *>(out_f16), (uint32_t)n_tiles, (uint32_t)nb);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -68,6 +68,8 @@ struct Model {
         uint32_t *toks = nullptr;
         float *X = nullptr, *H1 = nullptr, *Q = nullptr, *K = nullptr, *V = nullptr, *ATT = nullptr, *G = nullptr, *U = nullptr, *SC = nullptr;
         void *XN = nullptr, *QH = nullptr, *KH = nullptr, *VT = nullptr, *P = nullptr, *ACT = nullptr;  // fp16
+        void *WF16 = nullptr;      // one block's matrices widened to fp16 (K-quant models only, allocated on first use)
+        uint64_t wf16_bytes = 0;
     } pf;
     uint32_t pos_host = 0;
     hipGraph_t graph = nullptr;
@@ -602,7 +604,7 @@ NFAI_API int32_t nfai_hip_llama_destroy(nfai_model_t h)
                     m->q, m->att, m->act, m->logits, m->xn, m->qraw, m->scores, m->wts, m->proj, m->gate, m->up};
     for (void *p : ptrs) if (p) hipFree(p);
     void *pfp[] = {m->pf.toks, m->pf.X, m->pf.H1, m->pf.Q, m->pf.K, m->pf.V, m->pf.ATT, m->pf.G, m->pf.U, m->pf.SC,
-                   m->pf.XN, m->pf.QH, m->pf.KH, m->pf.VT, m->pf.P, m->pf.ACT};
+                   m->pf.XN, m->pf.QH, m->pf.KH, m->pf.VT, m->pf.P, m->pf.ACT, m->pf.WF16};
     for (void *p : pfp) if (p) hipFree(p);
     if (m->h_pin) hipHostFree(m->h_pin);
     m->magic = 0;
@@ -796,8 +798,26 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
     };
     const uint32_t QKV = HD + 2 * KD;
     HIP_TRY(hipMemcpyAsync(w.toks, tokens, (size_t)T * 4, hipMemcpyHostToDevice, s));
-    P_TRY(launch_embed_rows(m->token_embd.ptr, m->token_embd.type, w.toks, w.X, T, d.E, s));
-    for (Layer &L : m->layers) {
+    if (is_kquant(m->token_embd.type))
+        P_TRY(launch_embed_rows_kqt(m->token_embd.ptr, m->token_embd.type, m->token_embd.rows, w.toks, w.X, T, d.E, s));
+    else
+        P_TRY(launch_embed_rows(m->token_embd.ptr, m->token_embd.type, w.toks, w.X, T, d.E, s));
+    for (Layer &Lq : m->layers) {
+        // K-quant blocks: widen this block's seven matrices into the fp16 scratch (56 MB read + 201 MB written per
+        // block at 3B, ~50 us) and run the same GEMMs; fp16 blocks are used in place.
+        Layer L = Lq;
+        {
+            uint64_t off = 0;
+            for (Tensor *tq : {&L.wq, &L.wk, &L.wv, &L.wo, &L.wgate, &L.wup, &L.wdown}) {
+                if (tq->type == NFAI_F16) continue;
+                const uint64_t bytes = tq->rows * tq->cols * 2;
+                if (off + bytes > w.wf16_bytes) return fail(NFAI_ERR_STATE, "prefill: fp16 weight scratch too small");
+                void *dst = static_cast<uint8_t *>(w.WF16) + off;
+                P_TRY(launch_dequant_t16_f16(tq->ptr, tq->type, tq->rows, tq->cols, dst, s));
+                tq->ptr = dst; tq->type = NFAI_F16; tq->owned = false;
+                off += (bytes + 255) / 256 * 256;
+            }
+        }
         P_TRY(launch_rmsnorm_rows(w.X, static_cast<const float *>(L.attn_norm.ptr), w.XN, T, d.E, d.eps, s));
         P_TRY(gemm(w.XN, d.E, L.wq, &L.wk, &L.wv, w.Q, nullptr, QKV, d.E));              // q | k | v in one launch
         P_TRY(launch_rope_store_rows(w.Q, w.Q + HD, w.Q + HD + KD, w.QH, L.kcache, L.vcache, kvf16, m->kv_pos_stride, m->kv_head_stride,
@@ -846,10 +866,11 @@ static bool prefill_mfma_ok(const Model *m)
     if (m->pf.T == 0 || m->unfused || !(m->first_stage && m->last_stage)) return false;
     const nfai_llama_desc &d = m->d;
     if (d.E % 64 || d.F % 64 || (d.H * d.D) % 64 || (d.Hkv * d.D) % 64) return false;
-    if (m->token_embd.type != NFAI_F16 && m->token_embd.type != NFAI_F32) return false;
+    const int et = m->token_embd.type;
+    if (et != NFAI_F16 && et != NFAI_F32 && et != NFAI_Q4_K_T16 && et != NFAI_Q6_K_T16) return false;
     for (const Layer &L : m->layers)
         for (const Tensor *t : {&L.wq, &L.wk, &L.wv, &L.wo, &L.wgate, &L.wup, &L.wdown})
-            if (t->type != NFAI_F16) return false;
+            if (t->type != NFAI_F16 && t->type != NFAI_Q4_K_T16 && t->type != NFAI_Q6_K_T16) return false;
     return true;
 }
 
@@ -871,6 +892,19 @@ NFAI_API int32_t nfai_hip_llama_prefill(nfai_model_t h, const uint32_t *tokens, 
         return NFAI_OK;
     }
     hipStream_t s = m->ctx->stream;
+    if (!m->pf.WF16) {  // K-quant blocks: scratch for one block's matrices as fp16
+        uint64_t need = 0;
+        for (const Layer &L : m->layers) {
+            uint64_t b = 0;
+            for (const Tensor *t : {&L.wq, &L.wk, &L.wv, &L.wo, &L.wgate, &L.wup, &L.wdown})
+                if (t->type != NFAI_F16) b += (t->rows * t->cols * 2 + 255) / 256 * 256;
+            need = std::max(need, b);
+        }
+        if (need) {
+            DALLOC(m->pf.WF16, need);
+            m->pf.wf16_bytes = need;
+        }
+    }
     for (uint32_t done = 0; done < n;) {
         const uint32_t T = std::min(n - done, m->d.max_batch);
         int rc = prefill_chunk(m, tokens + done, T);

@@ -134,3 +134,44 @@ def test_qkv_rope_kquant_mixed_v(mgr, vq):
     assert total < sum(a.nbytes for a in w.values() if a.ndim == 2) * 0.45  # 4.5-6.6 bits instead of 16
     m.Dispose()
     mu.Dispose()
+
+
+@pytest.mark.parametrize("n,chunk", [(70, 64), (40, 128)], ids=["chunked", "one-chunk"])
+def test_prefill_mfma_kquant(mgr, n, chunk):
+    """Q4_K_M-style model (Q4_K blocks, attn_v / ffn_down / embeddings in Q6_K) through the batched MFMA prefill: each
+    block's matrices are widened to fp16 scratch and go through the fp16 GEMMs.  Oracle = token-by-token fp32 on the
+    dequantised weights; stated fp16 tolerance as for the fp16 prefill (tests/test_gpu_model.py): logits
+    max|d| <= 5e-2 * max(1, max|logit|), same argmax, decode continues from the prefilled cache."""
+    from nfai_amd.llama_model import LlamaModel, QuantTensor
+    dims = synth.TINY_D128
+    w = synth.make_weights(dims, seed=67, std=0.05)
+    wq, wref = {}, {}
+    for name, a in w.items():
+        if a.ndim == 1:
+            wq[name] = a
+            wref[name] = a
+            continue
+        qt = Q6_K if name.endswith(("attn_v.weight", "ffn_down.weight")) or name.startswith(("token_embd", "output.")) else Q4_K
+        raw, deq = quantize(a.astype(np.float32), qt)
+        wq[name] = QuantTensor(raw, qt, a.shape)
+        wref[name] = deq
+    dd = dict(E=dims.E, L=dims.L, H=dims.H, Hkv=dims.Hkv, D=dims.D, F=dims.F, V=dims.V, eps=1e-5, rope_dims=dims.D, rope_base=500000.0)
+    m = LlamaModel(mgr, synth.make_metadata(dims), wq, 160, dims=dd, max_batch=chunk)
+    ref = orc.OracleLlama(orc.LlamaDesc(E=dims.E, L=dims.L, H=dims.H, Hkv=dims.Hkv, D=dims.D, F=dims.F, V=dims.V, C=160), wref)
+    toks = synth.make_tokens(dims, n, seed=21)
+    want = None
+    for t in toks:
+        want = ref.step(int(t))
+    got = m.Prefill(toks)
+    assert m.Pos == n
+    tol5 = 5e-2 * max(1.0, float(np.abs(want).max()))
+    assert np.abs(got - want).max() <= tol5, np.abs(got - want).max()
+    assert int(np.argmax(got)) == orc.argmax(want)
+    np.testing.assert_allclose(m.ReadKV(dims.L - 1, False, n - 1), ref.kcache(dims.L - 1)[n - 1], rtol=0, atol=2e-2)
+    tok = orc.argmax(want)
+    for _ in range(6):
+        lg, am = m.Step(tok)
+        wl = ref.step(tok)
+        assert np.abs(lg - wl).max() <= tol5
+        tok = orc.argmax(wl)
+    m.Dispose()
