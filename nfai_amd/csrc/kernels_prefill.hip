@@ -39,6 +39,8 @@ struct GemmParams {
     uint64_t a_bs, b_bs, c_bs;   // batch strides (elements)
     uint32_t b_div;              // B batch index = batch / b_div (GQA: query heads share a kv head)
     float alpha;
+    uint32_t ksplit;             // > 1: blockIdx.z owns K tiles [z*KT/ksplit, (z+1)*KT/ksplit) and adds its product atomically
+                                 // into C, which the host has initialised with the residual (or zeros)
 };
 
 enum { EPI_F32 = 0, EPI_F16 = 1, EPI_SILU = 2 };
@@ -160,9 +162,9 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void k_gemm_f16(const GemmParams p
         }
     };
 
-    const uint32_t KT = p.K / BK;
+    const uint32_t KT = p.K / BK / p.ksplit, kt_base = blockIdx.z * KT;
 #pragma unroll
-    for (int r = 0; r < RING - 1; r++) load_tile(ra[r], rb[r], min((uint32_t)r, KT - 1));
+    for (int r = 0; r < RING - 1; r++) load_tile(ra[r], rb[r], kt_base + min((uint32_t)r, KT - 1));
     store_tile(ra[0], rb[0], 0);
     __syncthreads();
     // iteration kt: [request tile kt+RING-1 into the free register set] [MFMAs on tile kt] [tile kt+1: regs -> LDS]
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void k_gemm_f16(const GemmParams p
 #pragma unroll
         for (int r = 0; r < RING; r++) {
             const uint32_t kt = kt0 + r;
-            load_tile(ra[(r + RING - 1) % RING], rb[(r + RING - 1) % RING], min(kt + RING - 1, KT - 1));
+            load_tile(ra[(r + RING - 1) % RING], rb[(r + RING - 1) % RING], kt_base + min(kt + RING - 1, KT - 1));
             if (kt < KT) compute(kt & 1);
             store_tile(ra[(r + 1) % RING], rb[(r + 1) % RING], (kt + 1) & 1);
             __syncthreads();
@@ -229,6 +231,18 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void k_gemm_f16(const GemmParams p
                 }
     } else {
         float *Cb = static_cast<float *>(p.C) + (uint64_t)batch * p.c_bs;
+        if (p.ksplit > 1) {  // split-K: C already holds the residual (or zeros); every split adds its share
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const uint32_t row = rbase + i * 16 + r, col = n0 + cbase + j * 16;
+                        if (row < p.M) __hip_atomic_fetch_add(Cb + ((uint64_t)row * p.ldc + col), acc[i][j][r] * p.alpha, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+            return;
+        }
         const float *Rb = p.R ? p.R + (uint64_t)batch * p.c_bs : nullptr;
         // The residual is fetched for a whole row block first (rows clamped, no branch per element: a branch around
         // each load makes hipcc wait vmcnt(0) per element = dependent L2 round trips).
@@ -280,15 +294,39 @@ static hipError_t gemm_launch(const GemmParams &p, uint32_t batch, hipStream_t s
         }
     }
     const uint32_t tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles, batch), dim3(WM * WN * KS * 64), LDS, s, p);
+    hipLaunchKernelGGL(kern, dim3(tiles, batch, p.ksplit), dim3(WM * WN * KS * 64), LDS, s, p);
     return hipGetLastError();
 }
 
 template <int EPI>
-static hipError_t gemm_pick(const GemmParams &p, uint32_t batch, uint32_t n_cu, hipStream_t s)
+static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, hipStream_t s)
 {
     static const int env_big = getenv("NFAI_GEMM_BIG") ? atoi(getenv("NFAI_GEMM_BIG")) : 1;
     const uint64_t big_tiles = (uint64_t)((p.M + 127) / 128) * (p.N / 128) * batch;
+    if constexpr (EPI == EPI_F32) {
+        // Narrow outputs (N = E): too few 128 x 128 tiles for the chip, and the 128 x 64 configuration is LDS-bound
+        // (~370 TFLOP/s).  Split K over workgroups instead: ~1.5+ workgroups per CU of the efficient configuration,
+        // fp32 atomics into C, which is pre-set to the residual (or zero) by a device copy ahead of the launch.
+        // Measured (3B, T = 512): the Wo/Wdown launches 49.5 -> 45.2 us, QKV 43.5 -> 44.6 us, plus the copy that
+        // pre-sets C: 7.55 -> 7.75 ms per prefill.  Off by default (NFAI_GEMM_SPLITK=1 enables it).
+        static const int env_sk = getenv("NFAI_GEMM_SPLITK") ? atoi(getenv("NFAI_GEMM_SPLITK")) : 0;
+        const uint32_t KT = p.K / 64;
+        if (env_sk && env_big && batch == 1 && p.N % 128 == 0 && p.M >= 128 && big_tiles < (uint64_t)n_cu * 3 / 2) {
+            uint32_t ks = 0;
+            for (uint32_t c : {2u, 3u, 4u, 6u, 8u})
+                if (KT % c == 0 && KT / c >= 6 && big_tiles * c >= (uint64_t)n_cu * 3 / 2) { ks = c; break; }
+            if (ks) {
+                const size_t bytes = (size_t)p.M * p.ldc * sizeof(float);
+                hipError_t e = hipSuccess;
+                if (!p.R) e = hipMemsetAsync(p.C, 0, bytes, s);
+                else if (static_cast<const void *>(p.R) != p.C) e = hipMemcpyAsync(p.C, p.R, bytes, hipMemcpyDeviceToDevice, s);
+                if (e != hipSuccess) return e;
+                p.ksplit = ks;
+                p.R = nullptr;
+                return gemm_launch<128, 128, 2, 2, 64, EPI_F32>(p, batch, s);
+            }
+        }
+    }
     if (env_big && p.N % 128 == 0 && big_tiles >= (uint64_t)n_cu * 3 / 2) return gemm_launch<128, 128, 2, 2, 64, EPI>(p, batch, s);
     // at most ~one workgroup per CU: nothing else hides latency, so twice the bytes in flight and half the barriers
     static const int env_bk = getenv("NFAI_GEMM_BK128") ? atoi(getenv("NFAI_GEMM_BK128")) : 0;  // measured: 3 % slower than BK = 64
@@ -322,6 +360,7 @@ hipError_t launch_gemm_f16(const GemmArgs &a, hipStream_t s)
     p.C = a.C; p.R = a.R;
     p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldb = a.ldb; p.ldc = a.ldc;
     p.a_bs = a.a_bs; p.b_bs = a.b_bs; p.c_bs = a.c_bs; p.b_div = a.b_div ? a.b_div : 1; p.alpha = a.alpha;
+    p.ksplit = 1;
     const uint32_t batch = a.batch ? a.batch : 1;
     const uint32_t n_cu = a.n_cu ? a.n_cu : 256;
     if (a.epi == EPI_SILU) {
