@@ -98,6 +98,25 @@ __global__ void __launch_bounds__(512) k_stream_nosync(const u32x4* w, size_t wn
 
 __global__ void k_empty() {}
 
+// The dependency skeleton of one decode GEMV launch without its weights: every workgroup reads the 12 KB activation
+// vector the previous launch wrote, reduces it (RMSNorm-like), and writes its 12 outputs.  What a launch costs when the
+// weight stream is free: the floor of the per-kernel "fixed cost" in DESIGN.md 5.1.
+__global__ void __launch_bounds__(512) k_chain(const float* __restrict__ x, float* __restrict__ y, int n) {
+    __shared__ float red[8];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n / 4; i += blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    float tot = 0.f;
+    for (int i = 0; i < 8; i++) tot += red[i];
+    const int per = n / gridDim.x;
+    if (threadIdx.x < per) y[blockIdx.x * per + threadIdx.x] = x[blockIdx.x * per + threadIdx.x] * 0.5f + tot * 1e-9f;
+}
+
 int main() {
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
@@ -130,6 +149,27 @@ int main() {
     run("empty launches", 1000, [&](int it) { for (int i = 0; i < it; ++i) hipLaunchKernelGGL(k_empty, dim3(nb), dim3(512), 0, 0); }, 0);
     run("flat", 2000, [&](int it) { hipLaunchKernelGGL(k_flat, dim3(nb), dim3(512), 0, 0, ctr, it, err); }, 0);
     run("payload", 2000, [&](int it) { hipLaunchKernelGGL(k_payload, dim3(nb), dim3(512), 0, 0, ctr, data, it, err); }, 0);
+    {
+        float *xa, *xb;
+        CK(hipMalloc(&xa, 3072 * 4)); CK(hipMalloc(&xb, 3072 * 4));
+        CK(hipMemset(xa, 0, 3072 * 4)); CK(hipMemset(xb, 0, 3072 * 4));
+        run("chain (eager)", 1000, [&](int it) { for (int i = 0; i < it; ++i) hipLaunchKernelGGL(k_chain, dim3(nb), dim3(512), 0, 0, (i & 1) ? xb : xa, (i & 1) ? xa : xb, 3072); }, 0);
+        hipStream_t cs; CK(hipStreamCreate(&cs));
+        hipGraph_t g; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(k_chain, dim3(nb), dim3(512), 0, cs, (i & 1) ? xb : xa, (i & 1) ? xa : xb, 3072);
+        CK(hipStreamEndCapture(cs, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        CK(hipGraphLaunch(ge, cs)); CK(hipStreamSynchronize(cs));
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipEventRecord(e0, cs));
+            for (int k = 0; k < 5; ++k) CK(hipGraphLaunch(ge, cs));
+            CK(hipEventRecord(e1, cs));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("%-16s iters=%5d  %.3f us/iter\n", "chain (graph)", 1000, ms * 1e3 / 1000);
+        }
+    }
     const double bpi = (double)nb * 512 * 8 * 16;
     run("stream+sync", 2000, [&](int it) { hipLaunchKernelGGL(k_stream, dim3(nb), dim3(512), 0, 0, ctr, w, wn, it, err, sink); }, bpi);
     run("stream nosync", 2000, [&](int it) { hipLaunchKernelGGL(k_stream_nosync, dim3(nb), dim3(512), 0, 0, w, wn, it, sink); }, bpi);
