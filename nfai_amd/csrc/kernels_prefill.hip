@@ -39,6 +39,10 @@ struct GemmParams {
     uint64_t a_bs, b_bs, c_bs;   // batch strides (elements)
     uint32_t b_div;              // B batch index = batch / b_div (GQA: query heads share a kv head)
     float alpha;
+    uint32_t causal;             // 0: dense.  1: C = scores [query t][key s], tiles with only s > causal_pos0 + t are skipped
+                                 // (the softmax never reads them).  2: A = probabilities [t][s]: K tiles past the last
+                                 // unmasked key of the tile's rows are skipped (they multiply zeros).
+    uint32_t causal_pos0;
     uint32_t ksplit;             // > 1: blockIdx.z owns K tiles [z*KT/ksplit, (z+1)*KT/ksplit) and adds its product atomically
                                  // into C, which the host has initialised with the residual (or zeros)
 };
@@ -96,6 +100,7 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void k_gemm_f16(const GemmParams p
         }
     }
     const uint32_t m0 = mt_i * BM, n0 = nt_i * BN, batch = blockIdx.y;
+    if (p.causal == 1 && n0 > p.causal_pos0 + m0 + BM - 1) return;  // every (t, s) of this tile has s > pos0 + t
     const GLOBAL_AS uint8_t *Ab = (const GLOBAL_AS uint8_t *)(p.A + (uint64_t)batch * p.a_bs);
     // weight segment of this n tile (EPI_SILU: rows come from both segments, see b_row)
     const uint32_t seg = n0 < p.seg_end[0] ? 0u : (n0 < p.seg_end[1] ? 1u : 2u);
@@ -162,7 +167,9 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void k_gemm_f16(const GemmParams p
         }
     };
 
-    const uint32_t KT = p.K / BK / p.ksplit, kt_base = blockIdx.z * KT;
+    uint32_t KT = p.K / BK / p.ksplit;
+    const uint32_t kt_base = blockIdx.z * KT;
+    if (p.causal == 2) KT = min(KT, (p.causal_pos0 + m0 + BM + BK - 1) / BK);  // keys 0 .. pos0 + (last row of the tile)
 #pragma unroll
     for (int r = 0; r < RING - 1; r++) load_tile(ra[r], rb[r], kt_base + min((uint32_t)r, KT - 1));
     store_tile(ra[0], rb[0], 0);
@@ -361,6 +368,7 @@ hipError_t launch_gemm_f16(const GemmArgs &a, hipStream_t s)
     p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldb = a.ldb; p.ldc = a.ldc;
     p.a_bs = a.a_bs; p.b_bs = a.b_bs; p.c_bs = a.c_bs; p.b_div = a.b_div ? a.b_div : 1; p.alpha = a.alpha;
     p.ksplit = 1;
+    p.causal = a.causal; p.causal_pos0 = a.causal_pos0;
     const uint32_t batch = a.batch ? a.batch : 1;
     const uint32_t n_cu = a.n_cu ? a.n_cu : 256;
     if (a.epi == EPI_SILU) {

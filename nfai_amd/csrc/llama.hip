@@ -829,6 +829,7 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
             g.B = w.KH; g.ldb = d.D; g.b_bs = (uint64_t)Spad * d.D; g.b_div = G;
             g.C = w.SC; g.ldc = Spad; g.c_bs = (uint64_t)T * Spad;
             g.M = T; g.N = Spad; g.K = d.D; g.batch = d.H;
+            g.causal = 1; g.causal_pos0 = pos0;
             P_TRY(launch_gemm_f16(g, s));
         }
         P_TRY(launch_softmax_causal_rows(w.SC, w.P, d.H, T, Spad, pos0, 1.0f / sqrtf((float)d.D), s));
@@ -838,6 +839,7 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
             g.B = w.VT; g.ldb = Spad; g.b_bs = (uint64_t)d.D * Spad; g.b_div = G;
             g.C = w.XN; g.epi = 1; g.ldc = HD; g.c_bs = d.D;   // fp16 straight into the Wo GEMM's A operand
             g.M = T; g.N = d.D; g.K = Spad; g.batch = d.H;
+            g.causal = 2; g.causal_pos0 = pos0;
             P_TRY(launch_gemm_f16(g, s));
         }
         P_TRY(gemm(w.XN, HD, L.wo, nullptr, nullptr, w.H1, w.X, d.E, HD));                 // + residual (TransformerBlock.cs:153-158)
