@@ -67,6 +67,7 @@ struct GemvArgs {
     const void *W[3] = {nullptr, nullptr, nullptr};
     uint32_t seg_rows[3] = {0, 0, 0};
     int w_type = NFAI_F16;
+    uint32_t seg6_mask = 0;        // NFAI_KQ_MIXED: bit i = segment i is Q6_K_T16
     const float *x = nullptr;      // K floats
     const float *gamma = nullptr;  // non-null => RMSNorm(x, gamma, eps) prologue
     float eps = 0.f;
@@ -91,6 +92,7 @@ enum GemvMode { GEMV_PLAIN = 0, GEMV_RESIDUAL = 1, GEMV_QKV_ROPE = 2, GEMV_GATEU
 // Internal weight-type codes of the T16 layouts (kernels_gemv_kqm.hip): same bytes as the ggml type, rows
 // grouped in tiles of 16.  Never seen across the C ABI: uploads with rows % 16 == 0 are repacked into them.
 constexpr int NFAI_Q4_K_T16 = 112, NFAI_Q6_K_T16 = 114;
+constexpr int NFAI_KQ_MIXED = 115;  // GemvArgs::w_type of a q|k|v launch whose segments are Q4_K_T16 / Q6_K_T16 per seg6_mask
 inline bool is_kquant(int t) { return t == NFAI_Q4_K || t == NFAI_Q6_K || t == NFAI_Q4_K_T16 || t == NFAI_Q6_K_T16; }
 inline int ggml_type_of(int t) { return t == NFAI_Q4_K_T16 ? NFAI_Q4_K : (t == NFAI_Q6_K_T16 ? NFAI_Q6_K : t); }
 

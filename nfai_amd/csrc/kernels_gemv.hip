@@ -450,7 +450,7 @@ static hipError_t dispatch_mode(const GemvParams &p, const GemvPlan &pl, int mod
 
 hipError_t launch_gemv(const GemvArgs &a, hipStream_t s)
 {
-    if (a.w_type == NFAI_Q4_K_T16 || a.w_type == NFAI_Q6_K_T16) return launch_gemv_kqm(a, s);
+    if (a.w_type == NFAI_Q4_K_T16 || a.w_type == NFAI_Q6_K_T16 || a.w_type == NFAI_KQ_MIXED) return launch_gemv_kqm(a, s);
     if (a.w_type == NFAI_Q4_K || a.w_type == NFAI_Q6_K) return launch_gemv_kq(a, s);
     GemvParams p{};
     const int rpu = (a.mode == GEMV_QKV_ROPE || a.mode == GEMV_GATEUP) ? 2 : 1;

@@ -52,6 +52,7 @@ struct KqmParams {
     const float *gamma;
     float eps;
     uint32_t K, NB, NU, UB;
+    uint32_t seg6;             // NFAI_KQ_MIXED: bit i set = segment i is Q6_K (else Q4_K)
     float *y;
     const float *res;
     void *kc, *vc;
@@ -243,6 +244,10 @@ __device__ __forceinline__ void kqm_epilogue(const KqmParams &p, uint32_t u, uin
 template <int QT, int MODE, int BPW, bool NORM, int NS>
 __global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_kqt(const KqmParams p)
 {
+    // QT = NFAI_KQ_MIXED (QKV only): Q4_K and Q6_K segments in one launch (Q4_K_M files keep attn_v in Q6_K on half of
+    // the blocks); the activations are staged in both fragment layouts and every step branches on its segment's type.
+    constexpr bool HAS4 = QT != NFAI_Q6_K_T16, HAS6 = QT != NFAI_Q4_K_T16, MIXED = HAS4 && HAS6;
+    static_assert(!MIXED || MODE == GEMV_QKV_ROPE, "mixed encodings exist for the q|k|v launch only");
     using Regs = typename std::conditional<QT == NFAI_Q4_K_T16, Q4T, Q6T>::type;
     constexpr int R = MODE == GEMV_GATEUP ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -250,9 +255,11 @@ __global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_kqt(const KqmPara
     const uint32_t wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t kpad = nw * BPW * 256;
     const uint32_t UB = p.UB & 0xFFu;
-    uint8_t *xa = smem;                                               // kpad * 4 bytes: A fragments [blk][n][m][G][hl][8 x fp16]
-    float *sums = reinterpret_cast<float *>(smem + (size_t)kpad * 4);  // [blk][G] x {SX of sub-block 2G, of 2G+1} (+ pad)
-    uint8_t *zero = reinterpret_cast<uint8_t *>(sums + nw * BPW * 16);  // 1 KB of zeros
+    uint8_t *xa = smem;                                               // kpad * 4 bytes: A fragments [blk][slot][G][digit][16 B]
+    uint8_t *xa6 = MIXED ? smem + (size_t)kpad * 4 : xa;             // second fragment layout (Q6_K) when both are needed
+    float *sums = reinterpret_cast<float *>(xa6 + (size_t)kpad * 4);  // [blk][G][4]: sums of x' per scale group
+    float *sums6 = MIXED ? sums + nw * BPW * 16 : sums;
+    uint8_t *zero = reinterpret_cast<uint8_t *>(sums6 + nw * BPW * 16);  // 1 KB of zeros
     float *red = reinterpret_cast<float *>(zero + 1024);              // [2][UB][R][nw][64]
     float *scal = red + 2 * UB * R * nw * 64;                       // 32 floats of reduction scratch
 
@@ -286,8 +293,18 @@ __global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_kqt(const KqmPara
         const uint32_t blk = min(wid * BPW + bi, p.NB - 1);
         uint32_t seg, tile;
         kqm_unit<MODE>(p, u, tt, seg, tile);
-        if constexpr (QT == NFAI_Q4_K_T16) buf = q4t_load(p, seg, tile, blk, lane);
-        else buf = q6t_load(p, seg, tile, blk, lane);
+        if constexpr (QT == NFAI_Q4_K_T16) {
+            buf = q4t_load(p, seg, tile, blk, lane);
+        } else if constexpr (QT == NFAI_Q6_K_T16) {
+            buf = q6t_load(p, seg, tile, blk, lane);
+        } else {
+            if ((p.seg6 >> seg) & 1u) {
+                buf = q6t_load(p, seg, tile, blk, lane);
+            } else {
+                const Q4T q = q4t_load(p, seg, tile, blk, lane);
+                buf.qla = q.q0; buf.qlb = q.q1; buf.sc = q.hdr;
+            }
+        }
         ++ist;
     };
 #pragma unroll
@@ -351,21 +368,27 @@ __global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_kqt(const KqmPara
             //   Q4_K: k = blk*256 + (2G+n)*32 + hf*16 + j, slot = 2n + hf, sums per sub-block of 32 -> [blk][G][n]
             //   Q6_K: k = blk*256 + n*128 + qd*32 + lh*16 + j, G = 2n + lh, slot = qd, sums per group of 16 -> [blk][G][qd]
             const uint32_t blk = k >> 8, j = k & 15;
-            uint32_t g, slot, sidx;
-            if constexpr (QT == NFAI_Q4_K_T16) {
-                const uint32_t sb = (k >> 5) & 7, hf = (k >> 4) & 1;
-                g = sb >> 1; slot = (sb & 1) * 2 + hf; sidx = sb & 1;
-                sx = dpp_add8(sx);
-            } else {
-                g = ((k >> 7) & 1) * 2 + ((k >> 4) & 1); slot = (k >> 5) & 3; sidx = slot;
-                sx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0xB1, 0xF, 0xF, true));
-                sx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0x4E, 0xF, 0xF, true));
+            // sums over aligned groups of 4 lanes (16 elements) and of 8 lanes (32 elements)
+            sx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0xB1, 0xF, 0xF, true));
+            sx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0x4E, 0xF, 0xF, true));
+            const float sx16 = sx;
+            const float sx32 = sx + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0x141, 0xF, 0xF, true));
+            if constexpr (HAS4) {
+                const uint32_t sb = (k >> 5) & 7, hf = (k >> 4) & 1, g = sb >> 1, slot = (sb & 1) * 2 + hf;
+                uint8_t *frag = xa + (size_t)blk * 1024 + (slot * 4 + g) * 64 + j;
+                *reinterpret_cast<uint32_t *>(frag) = d0;
+                *reinterpret_cast<uint32_t *>(frag + 16) = d1;
+                *reinterpret_cast<uint32_t *>(frag + 32) = d2;
+                if ((lane & 7) == 0) sums[(blk * 4 + g) * 4 + (sb & 1)] = sx32;
             }
-            uint8_t *frag = xa + (size_t)blk * 1024 + (slot * 4 + g) * 64 + j;
-            *reinterpret_cast<uint32_t *>(frag) = d0;
-            *reinterpret_cast<uint32_t *>(frag + 16) = d1;
-            *reinterpret_cast<uint32_t *>(frag + 32) = d2;
-            if ((lane & (QT == NFAI_Q4_K_T16 ? 7 : 3)) == 0) sums[(blk * 4 + g) * 4 + sidx] = sx;
+            if constexpr (HAS6) {
+                const uint32_t g = ((k >> 7) & 1) * 2 + ((k >> 4) & 1), slot = (k >> 5) & 3;
+                uint8_t *frag = xa6 + (size_t)blk * 1024 + (slot * 4 + g) * 64 + j;
+                *reinterpret_cast<uint32_t *>(frag) = d0;
+                *reinterpret_cast<uint32_t *>(frag + 16) = d1;
+                *reinterpret_cast<uint32_t *>(frag + 32) = d2;
+                if ((lane & 3) == 0) sums6[(blk * 4 + g) * 4 + slot] = sx16;
+            }
         }
         __syncthreads();
     }
@@ -381,11 +404,27 @@ __global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_kqt(const KqmPara
         const uint32_t bc = wid * BPW + bi;
         const bool live = bc < p.NB;
         const uint32_t blk = min(bc, p.NB - 1);
-        const uint8_t *abase = a_live ? xa + (size_t)blk * 1024 + a_off : zero;
-        const f32x4 sm = *reinterpret_cast<const f32x4 *>(sums + (blk * 4 + g) * 4);
+        bool is6 = QT == NFAI_Q6_K_T16;
+        if constexpr (MIXED) {
+            uint32_t seg, tile;
+            kqm_unit<MODE>(p, blockIdx.x + ui * gridDim.x, tt, seg, tile);
+            is6 = (p.seg6 >> seg) & 1u;
+        }
         float a;
-        if constexpr (QT == NFAI_Q4_K_T16) a = q4t_dot(buf, abase, f32x2{sm[0], sm[1]}, g);
-        else a = q6t_dot(buf, abase, sm, g);
+        if (is6) {
+            if constexpr (HAS6) {
+                const uint8_t *abase = a_live ? xa6 + (size_t)blk * 1024 + a_off : zero;
+                const f32x4 sm = *reinterpret_cast<const f32x4 *>(sums6 + (blk * 4 + g) * 4);
+                a = q6t_dot(buf, abase, sm, g);
+            }
+        } else {
+            if constexpr (HAS4) {
+                const uint8_t *abase = a_live ? xa + (size_t)blk * 1024 + a_off : zero;
+                const f32x4 sm = *reinterpret_cast<const f32x4 *>(sums + (blk * 4 + g) * 4);
+                if constexpr (QT == NFAI_Q4_K_T16) a = q4t_dot(buf, abase, f32x2{sm[0], sm[1]}, g);
+                else a = q4t_dot(Q4T{buf.qla, buf.qlb, buf.sc}, abase, f32x2{sm[0], sm[1]}, g);
+            }
+        }
         acc += live ? a : 0.f;
         ++cst;
         if (bi == BPW - 1) {
@@ -676,7 +715,8 @@ static hipError_t q4t_bpw(const KqmParams &p, int bpw, uint32_t grid, uint32_t b
 
 hipError_t launch_gemv_kqm(const GemvArgs &a, hipStream_t s)
 {
-    if (a.w_type != NFAI_Q4_K_T16 && a.w_type != NFAI_Q6_K_T16) return hipErrorInvalidValue;
+    if (a.w_type != NFAI_Q4_K_T16 && a.w_type != NFAI_Q6_K_T16 && a.w_type != NFAI_KQ_MIXED) return hipErrorInvalidValue;
+    if (a.w_type == NFAI_KQ_MIXED && a.mode != GEMV_QKV_ROPE) return hipErrorInvalidValue;
     if (a.K == 0 || a.K % 256 != 0 || a.K > 16384) return hipErrorInvalidValue;
     KqmParams p{};
     uint32_t total_tiles = 0;
@@ -703,6 +743,7 @@ hipError_t launch_gemv_kqm(const GemvArgs &a, hipStream_t s)
     p.kv_pos_stride = a.kv_pos_stride; p.kv_head_stride = a.kv_head_stride;
     p.rope_cs = a.rope_cs; p.rope_dims = a.rope_dims; p.D = a.D ? a.D : 2; p.pos = a.pos_dev;
     p.kv_f16 = a.kv_type == NFAI_F16;
+    p.seg6 = a.seg6_mask;
     const int bpw = p.NB <= 16 ? 1 : (p.NB <= 32 ? 2 : 4);
     const uint32_t nw = (p.NB + bpw - 1) / bpw;
     static const int env_bpc = getenv("NFAI_KQM_BPC") ? atoi(getenv("NFAI_KQM_BPC")) : 1;  // sweep knobs
@@ -712,9 +753,11 @@ hipError_t launch_gemv_kqm(const GemvArgs &a, hipStream_t s)
     p.UB = min((uint32_t)max(1, min(env_ub, 8)), min(upb, nw));
     const int R = a.mode == GEMV_GATEUP ? 2 : 1;
     static const int env_xb = getenv("NFAI_KQM_XBAR") ? atoi(getenv("NFAI_KQM_XBAR")) : 0;
-    const size_t lds = (size_t)nw * bpw * 1024 + (size_t)nw * bpw * 64 + 1024 + (size_t)2 * p.UB * R * nw * 256 + 128;
+    const size_t nlay = a.w_type == NFAI_KQ_MIXED ? 2 : 1;  // fragment layouts staged
+    const size_t lds = nlay * ((size_t)nw * bpw * 1024 + (size_t)nw * bpw * 64) + 1024 + (size_t)2 * p.UB * R * nw * 256 + 128;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (env_xb) p.UB |= 0x100u;  // experiment flag, see the kernel
+    if (a.w_type == NFAI_KQ_MIXED) return q4t_bpw<NFAI_KQ_MIXED, GEMV_QKV_ROPE>(p, bpw, grid, nw * 64, lds, s);
     if (a.w_type == NFAI_Q4_K_T16) {
         switch (a.mode) {
             case GEMV_PLAIN: return q4t_bpw<NFAI_Q4_K_T16, GEMV_PLAIN>(p, bpw, grid, nw * 64, lds, s);

@@ -301,10 +301,16 @@ int block_fused(Model *m, Layer &L, Sched &sch)
         // One launch when q, k, v share an encoding; Q4_K_M files keep attn_v in Q6_K on some blocks:
         // then the segments that differ get their own launch (same kernel family, same epilogue).
         const Tensor *seg[3] = {&L.wq, &L.wk, &L.wv};
+        auto t16 = [](int ty) { return ty == NFAI_Q4_K_T16 || ty == NFAI_Q6_K_T16; };
         for (int first = 0; first < 3;) {
             int last = first;
-            while (last + 1 < 3 && seg[last + 1]->type == seg[first]->type) last++;
+            // segments of one encoding share a launch; so do T16 Q4_K and Q6_K segments (mixed kernel, kernels_gemv_kqm.hip)
+            while (last + 1 < 3 && (seg[last + 1]->type == seg[first]->type || (t16(seg[last + 1]->type) && t16(seg[first]->type)))) last++;
             GemvArgs a = gemv_base(m, *seg[first], m->x, d.E);
+            for (int i = first; i <= last; i++) {
+                if (seg[i]->type != seg[first]->type) a.w_type = NFAI_KQ_MIXED;
+                if (seg[i]->type == NFAI_Q6_K_T16) a.seg6_mask |= 1u << i;
+            }
             for (int i = 0; i < 3; i++) {
                 const bool in = i >= first && i <= last;
                 a.W[i] = in ? seg[i]->ptr : seg[first]->ptr;
