@@ -328,7 +328,13 @@ __global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_kqt(const KqmPara
         if (tid < 64) *reinterpret_cast<u32x4 *>(zero + tid * 16) = u32x4{0u, 0u, 0u, 0u};
         __syncthreads();
         float tss = 0.f, tam = 0.f;
-        for (uint32_t i = 0; i < nw; i++) { tss += scal[i]; tam = fmaxf(tam, scal[16 + i]); }
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) {  // fixed trip count: the 32 LDS reads issue back to back (a runtime bound serialises them)
+            const uint32_t ii = min(i, nw - 1);
+            const float s_i = scal[ii], m_i = scal[16 + ii];
+            tss += i < nw ? s_i : 0.f;
+            tam = fmaxf(tam, m_i);
+        }
         float rms = 1.f;
         if constexpr (NORM) {
             rms = sqrtf(tss / (float)p.K + p.eps);
@@ -440,8 +446,13 @@ __global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_kqt(const KqmPara
 #pragma unroll
                     for (int t2 = 0; t2 < R; t2++) {
                         const float *rp = red + (((par * UB + wid) * R + t2) * nw) * 64 + lane;
-                        float s = 0.f;
-                        for (uint32_t w = 0; w < nw; w++) s += rp[w * 64];
+                        float sp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (uint32_t w = 0; w < 16; w++) {  // fixed trip count, four independent chains
+                            const float v = rp[min(w, nw - 1) * 64];
+                            sp[w & 3] += w < nw ? v : 0.f;
+                        }
+                        float s = (sp[0] + sp[1]) + (sp[2] + sp[3]);
                         s += __shfl_xor(s, 16);
                         s += __shfl_xor(s, 32);
                         af[t2] = s * inv_scale;
