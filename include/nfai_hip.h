@@ -230,6 +230,10 @@ int32_t nfai_hip_llama_bytes_per_token(nfai_model_t model, uint32_t pos, uint64_
 /* Per-kernel-class device time (hipEvents around every launch of one eager step; slow path, for
  * bench.py's roofline object).  ids: 0 qkv, 1 attn, 2 wo, 3 gateup, 4 down, 5 lmhead, 6 other. */
 int32_t nfai_hip_llama_profile_step(nfai_model_t model, uint32_t token, float *ms_by_class /* 8 */, uint32_t *launches_by_class /* 8 */);
+/* Average duration (us) of ONE kernel class: all its launches of a decode step (one per block, each on its own weights)
+ * are replayed back to back, `reps` rounds, between a single pair of hipEvents on the launch stream (decode launches are
+ * idempotent).  This is the per-launch duration rocprofv3 --kernel-trace reports; bench.py's roofline uses it. */
+int32_t nfai_hip_llama_profile_kernel(nfai_model_t model, uint32_t token, int32_t kernel_class, uint32_t reps, float *us_avg);
 
 #ifdef __cplusplus
 }

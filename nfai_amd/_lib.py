@@ -97,6 +97,7 @@ SIGNATURES = {
     "nfai_hip_llama_read_kv": [H, u32, i32, u32, C.POINTER(f32)],
     "nfai_hip_llama_bytes_per_token": [H, u32, C.POINTER(u64), C.POINTER(u64)],
     "nfai_hip_llama_profile_step": [H, u32, C.POINTER(f32), C.POINTER(u32)],
+    "nfai_hip_llama_profile_kernel": [H, u32, i32, u32, C.POINTER(f32)],
 }
 
 _lib = None

@@ -85,6 +85,9 @@ struct Model {
     std::vector<hipEvent_t> ev;
     std::vector<int> ev_class;
     bool profiling = false;
+    int prof_rep_cls = -1;           // profile_kernel: class whose launches are collected and replayed back to back
+    std::vector<struct Op> prof_ops;
+    hipEvent_t prof_rep_ev[2] = {nullptr, nullptr};
 };
 
 Model *model_of(nfai_model_t h)
@@ -219,7 +222,10 @@ struct Sched {
         if (e != hipSuccess)
             return fail(e == hipErrorInvalidValue ? NFAI_ERR_INVALID : NFAI_ERR_HIP, "launch (class %d) failed: %s", op.cls,
                         hipGetErrorString(e));
-        return rec.end();
+        rc = rec.end();
+        if (rc) return rc;
+        if (m->profiling && m->prof_rep_cls == op.cls) m->prof_ops.push_back(op);  // replayed by profile_kernel
+        return NFAI_OK;
     }
     int submit(const Op &op)
     {
@@ -599,6 +605,7 @@ NFAI_API int32_t nfai_hip_llama_destroy(nfai_model_t h)
     if (m->stage_exec) hipGraphExecDestroy(m->stage_exec);
     if (m->stage_graph) hipGraphDestroy(m->stage_graph);
     for (hipEvent_t e : m->ev) hipEventDestroy(e);
+    for (hipEvent_t e : m->prof_rep_ev) if (e) hipEventDestroy(e);
     auto free_t = [](Tensor &t) { if (t.owned && t.ptr) hipFree(t.ptr); };
     free_t(m->token_embd); free_t(m->output_norm); free_t(m->output);
     for (Layer &L : m->layers) {
@@ -1098,6 +1105,47 @@ NFAI_API int32_t nfai_hip_llama_bytes_per_token(nfai_model_t h, uint32_t pos, ui
     }
     if (total) *total = t;
     if (dominant) *dominant = dom;
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_llama_profile_kernel(nfai_model_t h, uint32_t token, int32_t cls, uint32_t reps, float *us_avg)
+{
+    MODEL_OR_FAIL(m, h);
+    NEED_FINAL(m);
+    if (!us_avg || reps == 0 || cls < 0 || cls >= KC_N) return fail(NFAI_ERR_INVALID, "profile_kernel: bad arguments");
+    if (!(m->first_stage && m->last_stage)) return fail(NFAI_ERR_STATE, "profile_kernel: whole-model contexts only");
+    if (m->unfused) return fail(NFAI_ERR_STATE, "profile_kernel: fused path only");
+    int rc = set_token_async(m, token);
+    if (rc) return rc;
+    for (hipEvent_t e : m->ev) hipEventDestroy(e);
+    m->ev.clear();
+    m->ev_class.clear();
+    for (hipEvent_t &e : m->prof_rep_ev)
+        if (!e) HIP_TRY(hipEventCreate(&e));
+    m->prof_rep_cls = cls;
+    m->prof_ops.clear();
+    m->profiling = true;
+    rc = run_token(m);
+    m->profiling = false;
+    m->prof_rep_cls = -1;
+    if (rc) return rc;
+    if (m->prof_ops.empty()) return fail(NFAI_ERR_STATE, "profile_kernel: no launch of class %d in a step", cls);
+    // Replay: every launch of the class in a step (one per block: 28 different weight sets at 3B, far beyond the 256 MB
+    // Infinity Cache, so nothing is re-read from cache), `reps` rounds, back to back between ONE pair of events.  Decode
+    // launches are idempotent (outputs never alias inputs), so the replay leaves the model state as the step left it.
+    hipStream_t s = m->ctx->stream;
+    HIP_TRY(hipEventRecord(m->prof_rep_ev[0], s));
+    for (uint32_t r = 0; r < reps; r++)
+        for (const Op &op : m->prof_ops) {
+            hipError_t e = op.kind == 0 ? launch_gemv(op.g, s) : (op.kind == 1 ? launch_attn_decode(op.a, s) : op.f(s));
+            if (e != hipSuccess) return fail(NFAI_ERR_HIP, "profile_kernel: replay launch failed: %s", hipGetErrorString(e));
+        }
+    HIP_TRY(hipEventRecord(m->prof_rep_ev[1], s));
+    HIP_TRY(hipStreamSynchronize(s));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, m->prof_rep_ev[0], m->prof_rep_ev[1]));
+    *us_avg = ms * 1e3f / (float)((size_t)reps * m->prof_ops.size());
+    m->prof_ops.clear();
     return NFAI_OK;
 }
 

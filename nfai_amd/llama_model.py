@@ -208,6 +208,13 @@ class LlamaModel:
         names = ["qkv", "attn", "wo", "gateup", "down", "lmhead", "other"]
         return {k: (ms[i], n[i]) for i, k in enumerate(names)}
 
+    def ProfileKernel(self, token: int, kernel_class: str, reps: int = 4) -> float:
+        """Average duration in microseconds of one kernel class: its launches of a step replayed back to back, `reps` rounds."""
+        names = ["qkv", "attn", "wo", "gateup", "down", "lmhead", "other"]
+        us = C.c_float()
+        call("nfai_hip_llama_profile_kernel", self.handle, int(token), names.index(kernel_class), int(reps), C.byref(us))
+        return us.value
+
     # -- the token loop (LlamaModel.RunAsync, :99-174)
     def RunAsync(self, prompt: str, greedy: bool = False, max_tokens: int | None = None, rng=None):
         if self.tokenizer is None:
