@@ -1,35 +1,40 @@
-// kernels_gemv_kqm.hip — decode GEMV on ggml K-quant weights, second generation: the dequantised
-// nibbles are multiplied with the activations on the matrix cores (v_mfma_f32_16x16x32_f16 used as
-// 64 independent 8-wide dot products per instruction), the K-quant scales are applied in fp32.
+// kernels_gemv_kqm.hip — decode GEMV on ggml K-quant weights, second generation: the integer dot products
+// of the quantised weights with fixed-point activations run on the matrix cores (v_mfma_i32_16x16x64_i8 used as
+// 64 independent 16-wide dot products per instruction), the K-quant scales are applied in fp32.
 // Same op as kernels_gemv_kq.hip (MatrixMultiplyShader.cs:255-289 on weights the reference cannot
 // load at all, Parser.cs:111-114); that file stays as the path for row counts that are not a
 // multiple of 16.
 //
 // Why: kernels_gemv_kq.hip spends ~2.8 VALU operations per weight and lane (cvt + fma per nibble,
 // eight ds_read_b128 of activations per 32 weights) and runs at 1.8 TB/s on the gate/up matrix of
-// Llama-3.2-3B — VALU/LDS-bound at a quarter of what HBM delivers.  Here a nibble pair becomes a
-// packed fp16 pair with ONE v_and_or_b32 (0x5400 | nibble << 4 = 64 + nibble exactly), the
-// multiply-accumulate moves to MFMA, and the activations are read from LDS by 8 lanes per
-// instruction instead of 64: ~1.5 VALU operations per weight and lane.
+// Llama-3.2-3B — VALU/LDS-bound at a quarter of what HBM delivers.  Here four nibbles become four
+// byte operands with ONE v_and_b32 (q & 0x0F0F0F0F; the high nibbles one shift more), the multiply-
+// accumulate moves to MFMA, and the activations are read from LDS by 12 lanes per instruction
+// instead of 64: 0.375 (Q4_K) / 0.8 (Q6_K) VALU operations per weight and lane.
 //
-// Numerics: fp32 activations are split x*2^S = xh + xl/2048 into two fp16 values (S puts the largest
-// |x| near 2^13, so nothing on the path is an fp16 subnormal; 22 mantissa bits survive), the
-// integer weights (64 + q) are exact in fp16, products and sums are fp32 inside the MFMA; the offset
-// 64 * sum(xh + xl/2048) is subtracted in fp32.  Differences to the fp32 oracle are at the level of
-// fp32 summation-order noise (tests/test_gpu_kquant.py states the tolerance).
+// Numerics: each 256-element super-block of the activation vector (after the optional RMSNorm) is
+// scaled by a power of two so that |x * 2^S| < 2^22, rounded to an integer and split into three
+// signed base-256 digits; sum q * x' = S0 + 256 S1 + 65536 S2 is exact in int32, the K-quant scales
+// (d * sc, dmin * m, the -32 offset of Q6_K via the group sums of x') are applied in fp32 exactly
+// as ggml defines the block.  The only approximation is x' = round(x * 2^S): 24 bits relative to
+// the largest |x| of the super-block.  Against the fp32 oracle the differences are at the level of
+// fp32 summation-order noise (tests/test_gpu_kquant.py states the tolerance; max |dlogit| 1.5e-5 at 3B).
 //
 // HBM layout ("T16", repacked once at upload, same bytes): rows are grouped in tiles of 16.
 //   Q4_K: plane 0  [tile][blk][h:2][lane:64][16 B]  lane = G*16 + r holds qs[32G+16h .. +16) of row 16*tile+r,
 //                  i.e. lane group G owns sub-blocks 2G (low nibbles) and 2G+1 (high nibbles) of its row;
 //         plane 1  [tile][blk][r:16][16 B]          d, dmin, 12 scale bytes of row 16*tile+r.
-// Every wave-wide load is one contiguous kilobyte (qs) or 256 bytes (headers).
+//   Q6_K: see k_repack_q6k_t16.
+// Every wave-wide load is one contiguous kilobyte (quants) or 256 bytes (headers).
 //
 // Work split: a workgroup owns whole 16-row tiles ("units": one tile, or the gate and the up tile of
-// the same rows); its waves split K (wave w owns super-blocks w*BPW .. w*BPW+BPW-1 of every tile),
-// partial sums meet in LDS every UB units.  MFMA operand roles: A = activations (rows 4G / 4G+1 of
-// the 16x32 A matrix carry xh / xl for the k-slots of lane group G, zero elsewhere), B = weights
-// (column r = row r of the tile), so D[4G + {0,1}][r] lands in registers 0,1 of lane (G, r): every
-// lane receives the dot product of exactly the 8 weights it dequantised.
+// the same rows); its waves split K (wave w owns super-blocks w*BPW .. w*BPW+BPW-1 of every tile and
+// stages exactly those super-blocks of x: no workgroup barrier before the first dot product unless
+// the RMSNorm sum needs one), partial sums meet in LDS every UB units.  MFMA operand roles:
+// A = activations (rows 4G, 4G+1, 4G+2 of the 16x64 A matrix carry the three digits of the 16 k-slots
+// of lane group G, zero elsewhere), B = weights (column r = row r of the tile), so D[4G + {0,1,2}][r]
+// lands in registers 0..2 of lane (G, r): every lane receives the dot product of exactly the 16
+// weights it unpacked.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -102,9 +107,9 @@ __device__ __forceinline__ Q4T q4t_load(const KqmParams &p, uint32_t seg, uint32
 }
 
 // 64 weights of one lane (sub-blocks 2G: low nibbles, 2G+1: high nibbles) against the activations.
-// abase: this lane's A-fragment base in LDS (zero page for the lanes whose A rows are zero);
+// af: this lane's four A fragments (slot 2n + hf; all zero for the lanes whose A rows are zero);
 // sums = {SX[2G], SX[2G+1]} of this super-block.
-__device__ __forceinline__ float q4t_dot(const Q4T &w, const uint8_t *abase, f32x2 sums, uint32_t g)
+__device__ __forceinline__ float q4t_dot(const Q4T &w, const i32x4 (&af)[4], f32x2 sums, uint32_t g)
 {
     constexpr uint32_t M = 0x0F0F0F0Fu;
     i32x4 dlo = {0, 0, 0, 0}, dhi = {0, 0, 0, 0};
@@ -112,10 +117,8 @@ __device__ __forceinline__ float q4t_dot(const Q4T &w, const uint8_t *abase, f32
     for (int hf = 0; hf < 2; hf++) {
         const u32x4 q = hf ? w.q1 : w.q0;
         const u32x4 blo = q & M, bhi = (q >> 4) & M;  // 16 weights each, one byte per weight, k-slot j = byte j
-        const i32x4 alo = *reinterpret_cast<const i32x4 *>(abase + (0 * 2 + hf) * 256);
-        const i32x4 ahi = *reinterpret_cast<const i32x4 *>(abase + (1 * 2 + hf) * 256);
-        dlo = __builtin_amdgcn_mfma_i32_16x16x64_i8(alo, __builtin_bit_cast(i32x4, blo), dlo, 0, 0, 0);
-        dhi = __builtin_amdgcn_mfma_i32_16x16x64_i8(ahi, __builtin_bit_cast(i32x4, bhi), dhi, 0, 0, 0);
+        dlo = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[0 * 2 + hf], __builtin_bit_cast(i32x4, blo), dlo, 0, 0, 0);
+        dhi = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[1 * 2 + hf], __builtin_bit_cast(i32x4, bhi), dhi, 0, 0, 0);
     }
     // get_scale_min_k4 (ggml) for sub-blocks 2G and 2G+1, branch-free (see kernels_gemv_kq.hip)
     const float d = h2f_lo(w.hdr[0]), dmin = h2f_hi(w.hdr[0]);
@@ -159,7 +162,7 @@ __device__ __forceinline__ Q6T q6t_load(const KqmParams &p, uint32_t seg, uint32
 // 64 weights of one lane: half n = G>>1 of the super-block, columns l = 16*(G&1) .. +15 of all four quarters
 // (ggml dequantize_row_q6_K: quarter 0/2 = low/high nibbles of ql[l], quarter 1/3 = of ql[l+32], bits 2q..2q+1 of qh[l]);
 // one MFMA per quarter = one 16-weight scale group.  sums = sum of x' over each of the four groups.
-__device__ __forceinline__ float q6t_dot(const Q6T &w, const uint8_t *abase, f32x4 sums, uint32_t g)
+__device__ __forceinline__ float q6t_dot(const Q6T &w, const i32x4 (&af)[4], f32x4 sums, uint32_t g)
 {
     constexpr uint32_t M4 = 0x0F0F0F0Fu, M2 = 0x30303030u;
     const float d = h2f_lo(w.d);
@@ -170,8 +173,7 @@ __device__ __forceinline__ float q6t_dot(const Q6T &w, const uint8_t *abase, f32
         const u32x4 lo4 = (qd >= 2) ? ((ql >> 4) & M4) : (ql & M4);
         const u32x4 hs = qd == 0 ? (w.qh << 4) : (qd == 1 ? (w.qh << 2) : (qd == 2 ? w.qh : (w.qh >> 2)));
         const u32x4 b = (hs & M2) | lo4;  // unsigned 6-bit value per byte
-        const i32x4 a = *reinterpret_cast<const i32x4 *>(abase + qd * 256);
-        const i32x4 dq = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, __builtin_bit_cast(i32x4, b), i32x4{0, 0, 0, 0}, 0, 0, 0);
+        const i32x4 dq = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[qd], __builtin_bit_cast(i32x4, b), i32x4{0, 0, 0, 0}, 0, 0, 0);
         const float v = fmaf((float)dq[2], 65536.0f, fmaf((float)dq[1], 256.0f, (float)dq[0]));
         // scales[8n + (G&1) + 2*qd] of the row
         const uint32_t si = 8 * (g >> 1) + (g & 1) + 2 * qd;
@@ -259,21 +261,24 @@ __global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_kqt(const KqmPara
     uint8_t *xa6 = MIXED ? smem + (size_t)kpad * 4 : xa;             // second fragment layout (Q6_K) when both are needed
     float *sums = reinterpret_cast<float *>(xa6 + (size_t)kpad * 4);  // [blk][G][4]: sums of x' per scale group
     float *sums6 = MIXED ? sums + nw * BPW * 16 : sums;
-    uint8_t *zero = reinterpret_cast<uint8_t *>(sums6 + nw * BPW * 16);  // 1 KB of zeros
-    float *red = reinterpret_cast<float *>(zero + 1024);              // [2][UB][R][nw][64]
+    float *scl = sums6 + nw * BPW * 16;                               // [blk] 2^-S of the super-block's fixed-point scale
+    float *red = scl + nw * BPW;                                      // [2][UB][R][nw][64]
     float *scal = red + 2 * UB * R * nw * 64;                       // 32 floats of reduction scratch
 
     const uint32_t nunits = (p.NU - blockIdx.x + gridDim.x - 1) / gridDim.x;
     const uint32_t nsteps = nunits * R * BPW;  // step = (unit, tile of the unit, super-block of this wave)
 
-    // ---- activations first (vmcnt is in order: what the prologue needs must not queue behind weights)
+    // ---- activations first (vmcnt is in order: what the prologue needs must not queue behind weights).
+    // Wave w loads, scales and stages exactly the super-blocks it will consume (w*BPW .. w*BPW+BPW-1): the fixed-point
+    // scale is per super-block (a wave reduction, no LDS), and nothing staged here is read by another wave — the only
+    // workgroup barrier of the prologue is the one the RMSNorm sum needs.
     f32x4 xv[BPW], gv[NORM ? BPW : 1];
 #pragma unroll
     for (int i = 0; i < BPW; i++) {
-        const uint32_t k = (tid + i * blockDim.x) * 4;
-        const uint32_t kk = min(k, p.K - 4);
+        const uint32_t bw = wid * BPW + i;
+        const uint32_t kk = min(bw, p.NB - 1) * 256 + lane * 4;
         const f32x4 v = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.x + kk);
-        xv[i] = k < p.K ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        xv[i] = bw < p.NB ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (NORM) gv[i] = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.gamma + kk);
     }
 
@@ -310,44 +315,29 @@ __global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_kqt(const KqmPara
 #pragma unroll
     for (int j = 0; j < NBUF; j++) issue(buf[j]);
 
-    // ---- prologue: RMSNorm, power-of-two scale, fp16 hi/lo split -> LDS, sub-block sums
-    float inv_scale;
+    // ---- prologue: RMSNorm, per-super-block power-of-two scale, three base-256 digits -> LDS, scale-group sums
     {
-        float ss = 0.f, am = 0.f;
-#pragma unroll
-        for (int i = 0; i < BPW; i++) {
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                ss = fmaf(xv[i][e], xv[i][e], ss);
-                am = fmaxf(am, fabsf(NORM ? xv[i][e] * gv[i][e] : xv[i][e]));
-            }
-        }
-        ss = wave_sum(ss);
-        am = wave_max(am);
-        if (lane == 0) { scal[wid] = ss; scal[16 + wid] = am; }
-        if (tid < 64) *reinterpret_cast<u32x4 *>(zero + tid * 16) = u32x4{0u, 0u, 0u, 0u};
-        __syncthreads();
-        float tss = 0.f, tam = 0.f;
-#pragma unroll
-        for (uint32_t i = 0; i < 16; i++) {  // fixed trip count: the 32 LDS reads issue back to back (a runtime bound serialises them)
-            const uint32_t ii = min(i, nw - 1);
-            const float s_i = scal[ii], m_i = scal[16 + ii];
-            tss += i < nw ? s_i : 0.f;
-            tam = fmaxf(tam, m_i);
-        }
         float rms = 1.f;
         if constexpr (NORM) {
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < BPW; i++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) ss = fmaf(xv[i][e], xv[i][e], ss);
+            ss = wave_sum(ss);
+            if (lane == 0) scal[wid] = ss;
+            __syncthreads();
+            float tss = 0.f;
+#pragma unroll
+            for (uint32_t i = 0; i < 16; i++) {  // fixed trip count: the LDS reads issue back to back
+                const float s_i = scal[min(i, nw - 1)];
+                tss += i < nw ? s_i : 0.f;
+            }
             rms = sqrtf(tss / (float)p.K + p.eps);
-            tam = tam / rms;
         }
-        int S = 0;
-        if (tam > 0.f && tam < 3.0e38f) S = 21 - ilogbf(tam);  // |x * 2^S| < 2^22: a 24-bit signed integer after rounding
-        S = max(-100, min(100, S));
-        const float scale = ldexpf(1.0f, S);
-        inv_scale = ldexpf(1.0f, -S);
 #pragma unroll
         for (int i = 0; i < BPW; i++) {
-            const uint32_t k = (tid + i * blockDim.x) * 4;
+            const uint32_t blk = wid * BPW + i, k = lane * 4;  // position inside the super-block
             f32x4 v = xv[i];
             if constexpr (NORM) {
                 v[0] = (v[0] / rms) * gv[i][0];
@@ -355,6 +345,12 @@ __global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_kqt(const KqmPara
                 v[2] = (v[2] / rms) * gv[i][2];
                 v[3] = (v[3] / rms) * gv[i][3];
             }
+            const float am = wave_max(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            int S = 0;
+            if (am > 0.f && am < 3.0e38f) S = 21 - ilogbf(am);  // |x * 2^S| < 2^22: a 24-bit signed integer after rounding
+            S = max(-100, min(100, S));
+            const float scale = ldexpf(1.0f, S);
+            if (lane == 0) scl[blk] = ldexpf(1.0f, -S);
             uint32_t d0 = 0, d1 = 0, d2 = 0;  // digit planes of the four elements, one byte each
             float sx = 0.f;
 #pragma unroll
@@ -371,9 +367,9 @@ __global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_kqt(const KqmPara
                 sx += (float)xi;
             }
             // A fragments [blk][slot:4][G][digit][16 bytes]; a lane reads slot s at +256*s from its (G, digit) base.
-            //   Q4_K: k = blk*256 + (2G+n)*32 + hf*16 + j, slot = 2n + hf, sums per sub-block of 32 -> [blk][G][n]
-            //   Q6_K: k = blk*256 + n*128 + qd*32 + lh*16 + j, G = 2n + lh, slot = qd, sums per group of 16 -> [blk][G][qd]
-            const uint32_t blk = k >> 8, j = k & 15;
+            //   Q4_K: k = (2G+n)*32 + hf*16 + j, slot = 2n + hf, sums per sub-block of 32 -> [blk][G][n]
+            //   Q6_K: k = n*128 + qd*32 + lh*16 + j, G = 2n + lh, slot = qd, sums per group of 16 -> [blk][G][qd]
+            const uint32_t j = k & 15;
             // sums over aligned groups of 4 lanes (16 elements) and of 8 lanes (32 elements)
             sx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0xB1, 0xF, 0xF, true));
             sx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sx), 0x4E, 0xF, 0xF, true));
@@ -396,7 +392,7 @@ __global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_kqt(const KqmPara
                 if ((lane & 3) == 0) sums6[(blk * 4 + g) * 4 + slot] = sx16;
             }
         }
-        __syncthreads();
+        // no barrier: every LDS word written above is read only by this wave (LDS operations of a wave execute in order)
     }
 
     const uint32_t g = lane >> 4, ra = lane & 15;
@@ -417,21 +413,27 @@ __global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_kqt(const KqmPara
             is6 = (p.seg6 >> seg) & 1u;
         }
         float a;
+        // A fragments: only the lanes that carry digits read LDS (exec-masked), the rest supply zeros
+        const uint8_t *abase = (is6 ? xa6 : xa) + (size_t)blk * 1024 + a_off;
+        i32x4 af[4] = {i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}, i32x4{0, 0, 0, 0}};
+        if (a_live) {
+#pragma unroll
+            for (int sl = 0; sl < 4; sl++) af[sl] = *reinterpret_cast<const i32x4 *>(abase + sl * 256);
+        }
+        const float inv_scale = scl[blk];
         if (is6) {
             if constexpr (HAS6) {
-                const uint8_t *abase = a_live ? xa6 + (size_t)blk * 1024 + a_off : zero;
                 const f32x4 sm = *reinterpret_cast<const f32x4 *>(sums6 + (blk * 4 + g) * 4);
-                a = q6t_dot(buf, abase, sm, g);
+                a = q6t_dot(buf, af, sm, g);
             }
         } else {
             if constexpr (HAS4) {
-                const uint8_t *abase = a_live ? xa + (size_t)blk * 1024 + a_off : zero;
                 const f32x4 sm = *reinterpret_cast<const f32x4 *>(sums + (blk * 4 + g) * 4);
-                if constexpr (QT == NFAI_Q4_K_T16) a = q4t_dot(buf, abase, f32x2{sm[0], sm[1]}, g);
-                else a = q4t_dot(Q4T{buf.qla, buf.qlb, buf.sc}, abase, f32x2{sm[0], sm[1]}, g);
+                if constexpr (QT == NFAI_Q4_K_T16) a = q4t_dot(buf, af, f32x2{sm[0], sm[1]}, g);
+                else a = q4t_dot(Q4T{buf.qla, buf.qlb, buf.sc}, af, f32x2{sm[0], sm[1]}, g);
             }
         }
-        acc += live ? a : 0.f;
+        acc += live ? a * inv_scale : 0.f;
         ++cst;
         if (bi == BPW - 1) {
             const uint32_t slot = ui % UB;
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_kqt(const KqmPara
                         float s = (sp[0] + sp[1]) + (sp[2] + sp[3]);
                         s += __shfl_xor(s, 16);
                         s += __shfl_xor(s, 32);
-                        af[t2] = s * inv_scale;
+                        af[t2] = s;
                     }
                     kqm_epilogue<MODE>(p, uq, lane, af[0], af[R - 1], pre);
                 }
@@ -765,7 +767,7 @@ hipError_t launch_gemv_kqm(const GemvArgs &a, hipStream_t s)
     const int R = a.mode == GEMV_GATEUP ? 2 : 1;
     static const int env_xb = getenv("NFAI_KQM_XBAR") ? atoi(getenv("NFAI_KQM_XBAR")) : 0;
     const size_t nlay = a.w_type == NFAI_KQ_MIXED ? 2 : 1;  // fragment layouts staged
-    const size_t lds = nlay * ((size_t)nw * bpw * 1024 + (size_t)nw * bpw * 64) + 1024 + (size_t)2 * p.UB * R * nw * 256 + 128;
+    const size_t lds = nlay * ((size_t)nw * bpw * 1024 + (size_t)nw * bpw * 64) + (size_t)nw * bpw * 4 + (size_t)2 * p.UB * R * nw * 256 + 128;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (env_xb) p.UB |= 0x100u;  // experiment flag, see the kernel
     if (a.w_type == NFAI_KQ_MIXED) return q4t_bpw<NFAI_KQ_MIXED, GEMV_QKV_ROPE>(p, bpw, grid, nw * 64, lds, s);
