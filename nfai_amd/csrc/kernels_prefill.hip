@@ -460,9 +460,11 @@ hipError_t launch_rmsnorm_rows(const float *x, const float *g, void *y_f16, uint
 }
 
 // RoPE on T rows of q (-> fp16) and k (-> KV cache rows pos0+t), v -> cache rows.  One thread per pair.
+// kh / vt (optional): the fp16 K rows [Hkv][Spad][D] and V^T [Hkv][D][Spad] the attention GEMMs read are written here
+// for the chunk's own positions, so k_kv_to_f16 only has to convert positions < pos0 (nothing for a first chunk).
 __global__ void k_rope_store_rows(const float *q, const float *k, const float *v, _Float16 *qh, void *kc, void *vc, int kv_f16,
                                   uint64_t pos_stride, uint64_t head_stride, const float *freqs, uint32_t rope_dims, uint32_t H,
-                                  uint32_t Hkv, uint32_t D, uint32_t pos0, uint32_t ld)
+                                  uint32_t Hkv, uint32_t D, uint32_t pos0, uint32_t ld, _Float16 *kh, _Float16 *vt, uint32_t Spad)
 {
     const uint32_t t = blockIdx.y, half = D / 2;
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -494,28 +496,42 @@ __global__ void k_rope_store_rows(const float *q, const float *k, const float *v
             reinterpret_cast<float *>(base)[o] = o0;
             reinterpret_cast<float *>(base)[o + 1] = o1;
         }
+        if (kh) {
+            if (which == 1) {
+                _Float16 *dst = kh + ((uint64_t)h * Spad + pos) * D + pair;
+                dst[0] = (_Float16)o0;
+                dst[1] = (_Float16)o1;
+            } else {
+                vt[((uint64_t)h * D + pair) * Spad + pos] = (_Float16)o0;
+                vt[((uint64_t)h * D + pair + 1) * Spad + pos] = (_Float16)o1;
+            }
+        }
     }
 }
 
 hipError_t launch_rope_store_rows(const float *q, const float *k, const float *v, void *qh, void *kc, void *vc, int kv_f16,
                                   uint64_t pos_stride, uint64_t head_stride, const float *freqs, uint32_t rope_dims, uint32_t H,
-                                  uint32_t Hkv, uint32_t D, uint32_t pos0, uint32_t T, uint32_t ld, hipStream_t s)
+                                  uint32_t Hkv, uint32_t D, uint32_t pos0, uint32_t T, uint32_t ld, void *kh, void *vt, uint32_t Spad,
+                                  hipStream_t s)
 {
     const uint32_t n = (H + 2 * Hkv) * D / 2;
     k_rope_store_rows<<<dim3((n + 255) / 256, T), 256, 0, s>>>(q, k, v, static_cast<_Float16 *>(qh), kc, vc, kv_f16, pos_stride,
-                                                               head_stride, freqs, rope_dims, H, Hkv, D, pos0, ld);
+                                                               head_stride, freqs, rope_dims, H, Hkv, D, pos0, ld,
+                                                               static_cast<_Float16 *>(kh), static_cast<_Float16 *>(vt), Spad);
     return hipGetLastError();
 }
 
 // KV cache (fp32 or fp16, strided) -> fp16 K [Hkv][Spad][D] and V^T [Hkv][D][Spad] for positions < S
 // (rows S..Spad-1 / columns S..Spad-1 are zero so the padded GEMMs see zeros).
+// skip_lo..skip_hi-1: positions another kernel fills (the chunk's own rows, written by k_rope_store_rows)
 __global__ void k_kv_to_f16(const void *kc, const void *vc, int kv_f16, uint64_t pos_stride, uint64_t head_stride, _Float16 *kh,
-                            _Float16 *vt, uint32_t Hkv, uint32_t D, uint32_t S, uint32_t Spad)
+                            _Float16 *vt, uint32_t Hkv, uint32_t D, uint32_t S, uint32_t Spad, uint32_t skip_lo, uint32_t skip_hi)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t n = (uint64_t)Hkv * Spad * D;
     if (i >= n) return;
     const uint32_t d = i % D, sp = (i / D) % Spad, h = i / ((uint64_t)D * Spad);
+    if (sp >= skip_lo && sp < skip_hi) return;
     float kvv = 0.f, vvv = 0.f;
     if (sp < S) {
         const uint64_t o = (uint64_t)sp * pos_stride + (uint64_t)h * head_stride + d;
@@ -532,11 +548,12 @@ __global__ void k_kv_to_f16(const void *kc, const void *vc, int kv_f16, uint64_t
 }
 
 hipError_t launch_kv_to_f16(const void *kc, const void *vc, int kv_f16, uint64_t pos_stride, uint64_t head_stride, void *kh, void *vt,
-                            uint32_t Hkv, uint32_t D, uint32_t S, uint32_t Spad, hipStream_t s)
+                            uint32_t Hkv, uint32_t D, uint32_t S, uint32_t Spad, uint32_t skip_lo, uint32_t skip_hi, hipStream_t s)
 {
+    if (skip_lo == 0 && skip_hi >= Spad) return hipSuccess;  // a first chunk that fills the padded length exactly
     const uint64_t n = (uint64_t)Hkv * Spad * D;
     k_kv_to_f16<<<(uint32_t)((n + 255) / 256), 256, 0, s>>>(kc, vc, kv_f16, pos_stride, head_stride, static_cast<_Float16 *>(kh),
-                                                            static_cast<_Float16 *>(vt), Hkv, D, S, Spad);
+                                                            static_cast<_Float16 *>(vt), Hkv, D, S, Spad, skip_lo, skip_hi);
     return hipGetLastError();
 }
 

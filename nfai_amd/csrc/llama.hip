@@ -834,8 +834,9 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
         P_TRY(launch_rmsnorm_rows(w.X, static_cast<const float *>(L.attn_norm.ptr), w.XN, T, d.E, d.eps, s));
         P_TRY(gemm(w.XN, d.E, L.wq, &L.wk, &L.wv, w.Q, nullptr, QKV, d.E));              // q | k | v in one launch
         P_TRY(launch_rope_store_rows(w.Q, w.Q + HD, w.Q + HD + KD, w.QH, L.kcache, L.vcache, kvf16, m->kv_pos_stride, m->kv_head_stride,
-                                     m->d_freqs, d.rope_dims, d.H, d.Hkv, d.D, pos0, T, QKV, s));
-        P_TRY(launch_kv_to_f16(L.kcache, L.vcache, kvf16, m->kv_pos_stride, m->kv_head_stride, w.KH, w.VT, d.Hkv, d.D, S, Spad, s));
+                                     m->d_freqs, d.rope_dims, d.H, d.Hkv, d.D, pos0, T, QKV, w.KH, w.VT, Spad, s));
+        // earlier positions (chunked prompts) and the zero padding; the chunk's own rows were written above
+        P_TRY(launch_kv_to_f16(L.kcache, L.vcache, kvf16, m->kv_pos_stride, m->kv_head_stride, w.KH, w.VT, d.Hkv, d.D, S, Spad, pos0, S, s));
         {   // scores[h][t][s] = q_h[t] . k_kvh[s]   (scaling and the causal limit are applied by the softmax)
             GemmArgs g;
             g.A = w.QH; g.lda = HD; g.a_bs = d.D;
