@@ -239,6 +239,7 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
         if constexpr (NORM) gv[i] = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.gamma + kk);
     }
 
+    __builtin_amdgcn_sched_barrier(0);  // the activation loads stay first in program order (vmcnt retires in order)
     // lane q < UPW finishes unit q of each group: what its FIRST epilogue reads (residual element /
     // cos,sin pair) and the position are requested now, with the activations
     float e0 = 0.f, e1 = 0.f;

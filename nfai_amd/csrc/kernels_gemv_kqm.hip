@@ -241,10 +241,12 @@ __device__ __forceinline__ void kqm_epilogue(const KqmParams &p, uint32_t u, uin
     }
 }
 
-// NS > 0: no workgroup has more than NS steps — all of them are issued before the prologue and consumed
-// in a straight line (the common case for the per-block matrices of a 3B model: 1-4 steps per wave).
+// NS > 0 (1 or 2): no workgroup has more than NS steps — all of them are issued before the prologue and consumed
+// in a straight line (the common case for the per-block matrices of a 3B model).  NS = 0: ping-pong over two buffers.
+// (Measured and dropped: an s_barrier between the activation loads and the first weight loads, so that no wave's x
+// queues behind another wave's weights — no effect; four steps in flight — slower, see the step list in DESIGN.md.)
 template <int QT, int MODE, int BPW, bool NORM, int NS>
-__global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_kqt(const KqmParams p)
+__global__ __launch_bounds__(1024) void k_gemv_kqt(const KqmParams p)
 {
     // QT = NFAI_KQ_MIXED (QKV only): Q4_K and Q6_K segments in one launch (Q4_K_M files keep attn_v in Q6_K on half of
     // the blocks); the activations are staged in both fragment layouts and every step branches on its segment's type.
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_kqt(const KqmPara
     const uint32_t tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
     const uint32_t wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t kpad = nw * BPW * 256;
-    const uint32_t UB = p.UB & 0xFFu;
+    const uint32_t UB = p.UB;
     uint8_t *xa = smem;                                               // kpad * 4 bytes: A fragments [blk][slot][G][digit][16 B]
     uint8_t *xa6 = MIXED ? smem + (size_t)kpad * 4 : xa;             // second fragment layout (Q6_K) when both are needed
     float *sums = reinterpret_cast<float *>(xa6 + (size_t)kpad * 4);  // [blk][G][4]: sums of x' per scale group
@@ -282,10 +284,9 @@ __global__ __launch_bounds__(NS == 4 ? 768 : 1024) void k_gemv_kqt(const KqmPara
         if constexpr (NORM) gv[i] = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.gamma + kk);
     }
 
-    // Every wave of the workgroup has its activation loads in the memory pipeline before any wave queues
-    // weights behind them (the pipeline is shared in order: a late wave's x would otherwise wait behind the
-    // early waves' kilobytes of weights, and the prologue needs the x of ALL waves).  s_barrier only: no waitcnt.
-    if (p.UB & 0x100u) __builtin_amdgcn_s_barrier();
+    // keep the activation loads FIRST in program order (vmcnt retires in order: the prologue must not wait behind
+    // weights): without this fence hipcc's scheduler interleaves the loads below with them (measured: -2.5 % tokens/s)
+    __builtin_amdgcn_sched_barrier(0);
     const KqmPre pre0 = kqm_preload<MODE>(p, min(blockIdx.x + wid * gridDim.x, p.NU - 1), lane);  // epilogue inputs of round 0
     // ---- weights of the first steps
     constexpr int NBUF = NS > 0 ? NS : 2;
@@ -765,11 +766,9 @@ hipError_t launch_gemv_kqm(const GemvArgs &a, hipStream_t s)
     const uint32_t upb = (p.NU + grid - 1) / grid;
     p.UB = min((uint32_t)max(1, min(env_ub, 8)), min(upb, nw));
     const int R = a.mode == GEMV_GATEUP ? 2 : 1;
-    static const int env_xb = getenv("NFAI_KQM_XBAR") ? atoi(getenv("NFAI_KQM_XBAR")) : 0;
     const size_t nlay = a.w_type == NFAI_KQ_MIXED ? 2 : 1;  // fragment layouts staged
     const size_t lds = nlay * ((size_t)nw * bpw * 1024 + (size_t)nw * bpw * 64) + (size_t)nw * bpw * 4 + (size_t)2 * p.UB * R * nw * 256 + 128;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    if (env_xb) p.UB |= 0x100u;  // experiment flag, see the kernel
     if (a.w_type == NFAI_KQ_MIXED) return q4t_bpw<NFAI_KQ_MIXED, GEMV_QKV_ROPE>(p, bpw, grid, nw * 64, lds, s);
     if (a.w_type == NFAI_Q4_K_T16) {
         switch (a.mode) {
