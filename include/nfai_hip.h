@@ -145,6 +145,12 @@ int32_t nfai_hip_attn_decode(nfai_ctx_t ctx, nfai_buf_t q, nfai_buf_t kcache, nf
                              uint32_t H, uint32_t Hkv, uint32_t D, uint32_t S, uint32_t C, int32_t kv_type);
 /* [RMSNorm ->] GEMV [-> + residual]: y = res + W * (norm ? rmsnorm(x, gamma) : x).  gamma / res
  * may be 0 (absent). */
+/* Batched form of MatrixMultiplyShader (inputRowCount = M > 1, which the reference never uses: MatrixMultiplyShader.cs:31-47
+ * takes the row count, TransformerBlock.cs:47-101 always passes 1): C[M][N] fp32 (+ residual R, may be 0) = A[M][K] * W[N][K]^T
+ * with fp16 operands on the matrix cores — the GEMM of the MFMA prefill, exposed for tests and tools.  variant: 0 = chosen
+ * from the shape, 1 = 128x64 tiles, 2 = 128x128 tiles, 3 / 4 = direct-to-LDS staging with 2 / 3 stages (N %% 128 == 0). */
+int32_t nfai_hip_gemm_f16(nfai_ctx_t ctx, nfai_buf_t A_f16, nfai_buf_t W_f16, nfai_buf_t R, nfai_buf_t C, uint32_t M, uint32_t N,
+                          uint32_t K, int32_t variant);
 int32_t nfai_hip_gemv_fused(nfai_ctx_t ctx, nfai_buf_t W, int32_t w_type, nfai_buf_t x, nfai_buf_t gamma,
                             float eps, nfai_buf_t res, nfai_buf_t y, uint32_t N, uint32_t K);
 /* RMSNorm -> Wgate, Wup GEMVs -> SiLU(gate) * up (TransformerBlock.cs:163-171 in one launch). */

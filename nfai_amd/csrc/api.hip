@@ -575,6 +575,31 @@ NFAI_API int32_t nfai_hip_attn_decode(nfai_ctx_t h, nfai_buf_t q, nfai_buf_t kc,
     return NFAI_OK;
 }
 
+NFAI_API int32_t nfai_hip_gemm_f16(nfai_ctx_t h, nfai_buf_t A, nfai_buf_t W, nfai_buf_t R, nfai_buf_t C, uint32_t M, uint32_t N, uint32_t K,
+                                   int32_t variant)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(ba, A);
+    BUF_OR_FAIL(bw, W);
+    BUF_OR_FAIL(bc, C);
+    Buf *br = R ? buf_of(R) : nullptr;
+    if (R && !br) return fail(NFAI_ERR_INVALID, "gemm_f16: invalid residual handle");
+    if (M == 0 || N % 64 || K % 64 || K == 0) return fail(NFAI_ERR_INVALID, "gemm_f16: needs M > 0, N %% 64 == 0, K %% 64 == 0 (M=%u N=%u K=%u)", M, N, K);
+    NEED(ba, (uint64_t)M * K, 2);
+    NEED(bw, (uint64_t)N * K, 2);
+    NEED(bc, (uint64_t)M * N, 4);
+    if (br) NEED(br, (uint64_t)M * N, 4);
+    GemmArgs g;
+    g.A = ba->ptr; g.lda = K; g.B = bw->ptr; g.ldb = K; g.C = bc->ptr; g.ldc = N;
+    g.R = br ? static_cast<const float *>(br->ptr) : nullptr;
+    g.M = M; g.N = N; g.K = K; g.variant = variant;
+    g.n_cu = (uint32_t)c->prop.multiProcessorCount;
+    hipError_t e = launch_gemm_f16(g, c->stream);
+    if (e == hipErrorInvalidValue) return fail(NFAI_ERR_INVALID, "gemm_f16: unsupported shape / variant %d (M=%u N=%u K=%u)", variant, M, N, K);
+    if (e != hipSuccess) return fail(NFAI_ERR_HIP, "gemm_f16: launch failed: %s", hipGetErrorString(e));
+    return NFAI_OK;
+}
+
 NFAI_API int32_t nfai_hip_gemv_fused(nfai_ctx_t h, nfai_buf_t W, int32_t type, nfai_buf_t x, nfai_buf_t gamma, float eps,
                                      nfai_buf_t res, nfai_buf_t y, uint32_t N, uint32_t K)
 {

@@ -64,6 +64,87 @@ template <int CH> __device__ __forceinline__ uint32_t lds_off(uint32_t row, uint
 // EPI_SILU: the tile's columns are 32 gate | 32 up rows of the SAME 32 outputs per 64-column wave slice, so
 // act = up * silu(gate) is formed in registers and written as fp16 (SiLUShader + ElementWiseMultiplicationShader
 // fused into the GEMM: no fp32 gate/up round trip through HBM).
+// Epilogue shared by the GEMM kernels: accumulators of one wave tile -> C (fp32 + residual / fp16 / SiLU*up fp16 / split-K atomics).
+template <int BM, int BN, int WM, int WN, int EPI, int TM, int TN>
+__device__ __forceinline__ void gemm_store(f32x4 (&acc)[TM][TN], const GemmParams &p, uint32_t m0, uint32_t n0, uint32_t wm, uint32_t wn,
+                                           uint32_t lane, uint32_t batch)
+{
+    // C/D layout of mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg.
+    const uint32_t rbase = m0 + wm * (BM / WM) + (lane >> 4) * 4, cbase = wn * (BN / WN) + (lane & 15);
+    if constexpr (EPI == EPI_SILU) {
+        _Float16 *Ch = static_cast<_Float16 *>(p.C) + (uint64_t)batch * p.c_bs;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t row = rbase + i * 16 + r, col = n0 / 2 + wn * 32 + j * 16 + (lane & 15);
+                    const float g = acc[i][j][r] * p.alpha, u = acc[i][j + 2][r] * p.alpha;
+                    if (row < p.M) Ch[(uint64_t)row * p.ldc + col] = (_Float16)(u * silu_ref(g));
+                }
+    } else if constexpr (EPI == EPI_F16) {
+        _Float16 *Ch = static_cast<_Float16 *>(p.C) + (uint64_t)batch * p.c_bs;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t row = rbase + i * 16 + r, col = n0 + cbase + j * 16;
+                    if (row < p.M) Ch[(uint64_t)row * p.ldc + col] = (_Float16)(acc[i][j][r] * p.alpha);
+                }
+    } else {
+        float *Cb = static_cast<float *>(p.C) + (uint64_t)batch * p.c_bs;
+        if (p.ksplit > 1) {  // split-K: C already holds the residual (or zeros); every split adds its share
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const uint32_t row = rbase + i * 16 + r, col = n0 + cbase + j * 16;
+                        if (row < p.M) __hip_atomic_fetch_add(Cb + ((uint64_t)row * p.ldc + col), acc[i][j][r] * p.alpha, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+            return;
+        }
+        const float *Rb = p.R ? p.R + (uint64_t)batch * p.c_bs : nullptr;
+        // The residual is fetched for a whole row block first (rows clamped, no branch per element: a branch around
+        // each load makes hipcc wait vmcnt(0) per element = dependent L2 round trips).
+        if (Rb) {
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                float rv[TN][4];
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const uint32_t row = min(rbase + i * 16 + r, p.M - 1), col = n0 + cbase + j * 16;
+                        rv[j][r] = *((const GLOBAL_AS float *)Rb + ((uint64_t)row * p.ldc + col));
+                    }
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[i][j][r] = fmaf(acc[i][j][r], p.alpha, rv[j][r]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j] *= p.alpha;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t row = rbase + i * 16 + r, col = n0 + cbase + j * 16;
+                    if (row < p.M) Cb[(uint64_t)row * p.ldc + col] = acc[i][j][r];
+                }
+    }
+}
+
 // KS > 1: KS wave groups share the tile and split every K tile's k-steps between them (twice the waves per SIMD to
 // overlap fragment reads, MFMAs and staging when only ~one workgroup fits or exists per CU); their accumulators
 // meet in LDS once, after the K loop.
@@ -211,80 +292,130 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void k_gemm_f16(const GemmParams p
 #pragma unroll
                 for (int j = 0; j < TN; j++) acc[i][j] += park[((((g - 1) * (WM * WN) + wave) * TM + i) * TN + j) * 64 + lane];
     }
-    // C/D layout of mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg.
-    const uint32_t rbase = m0 + wm * (BM / WM) + (lane >> 4) * 4, cbase = wn * (BN / WN) + (lane & 15);
-    if constexpr (EPI == EPI_SILU) {
-        _Float16 *Ch = static_cast<_Float16 *>(p.C) + (uint64_t)batch * p.c_bs;
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const uint32_t row = rbase + i * 16 + r, col = n0 / 2 + wn * 32 + j * 16 + (lane & 15);
-                    const float g = acc[i][j][r] * p.alpha, u = acc[i][j + 2][r] * p.alpha;
-                    if (row < p.M) Ch[(uint64_t)row * p.ldc + col] = (_Float16)(u * silu_ref(g));
-                }
-    } else if constexpr (EPI == EPI_F16) {
-        _Float16 *Ch = static_cast<_Float16 *>(p.C) + (uint64_t)batch * p.c_bs;
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const uint32_t row = rbase + i * 16 + r, col = n0 + cbase + j * 16;
-                    if (row < p.M) Ch[(uint64_t)row * p.ldc + col] = (_Float16)(acc[i][j][r] * p.alpha);
-                }
-    } else {
-        float *Cb = static_cast<float *>(p.C) + (uint64_t)batch * p.c_bs;
-        if (p.ksplit > 1) {  // split-K: C already holds the residual (or zeros); every split adds its share
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const uint32_t row = rbase + i * 16 + r, col = n0 + cbase + j * 16;
-                        if (row < p.M) __hip_atomic_fetch_add(Cb + ((uint64_t)row * p.ldc + col), acc[i][j][r] * p.alpha, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-            return;
-        }
-        const float *Rb = p.R ? p.R + (uint64_t)batch * p.c_bs : nullptr;
-        // The residual is fetched for a whole row block first (rows clamped, no branch per element: a branch around
-        // each load makes hipcc wait vmcnt(0) per element = dependent L2 round trips).
-        if (Rb) {
-#pragma unroll
-            for (int i = 0; i < TM; i++) {
-                float rv[TN][4];
-#pragma unroll
-                for (int j = 0; j < TN; j++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const uint32_t row = min(rbase + i * 16 + r, p.M - 1), col = n0 + cbase + j * 16;
-                        rv[j][r] = *((const GLOBAL_AS float *)Rb + ((uint64_t)row * p.ldc + col));
-                    }
-#pragma unroll
-                for (int j = 0; j < TN; j++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) acc[i][j][r] = fmaf(acc[i][j][r], p.alpha, rv[j][r]);
-            }
+    gemm_store<BM, BN, WM, WN, EPI, TM, TN>(acc, p, m0, n0, wm, wn, lane, batch);
+}
+
+// ---- direct-to-LDS variant (128 x 128 x 64 tile, 2 x 2 waves of 64 x 64) ---------------------------------------------
+// Operands go global -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write pass); NST LDS stages, tile kt + NST - 1
+// is requested while tile kt is multiplied.  One raw s_barrier per K tile:
+//     s_waitcnt vmcnt(8 (NST - 2))   my share of tile kt has landed (tiles kt+1 .. kt+NST-2 may still be in flight)
+//     s_barrier                      everybody's share has; everybody is past the MFMAs of tile kt-1
+//     8 x global_load_lds            tile kt+NST-1 -> the stage tile kt-1 just vacated (past the end: the last tile again,
+//                                    into a stage nobody reads any more — the counts stay uniform, nothing is conditional)
+//     MFMAs on tile kt
+// An LDS-DMA instruction writes lane-linear (wave-uniform base + lane * 16 B): the XOR swizzle of the fragment reads is
+// applied to the SOURCE address instead (LDS slot (row, c') receives global chunk c' ^ (row & 7)).  Plain __syncthreads()
+// would drain the DMAs (its fence waits vmcnt(0)), hence the raw barrier + counted waits (MI355X guide, §5).
+template <int EPI, int NST>
+__global__ __launch_bounds__(256) void k_gemm_f16_glds(const GemmParams p)
+{
+    constexpr int BM = 128, BN = 128, BK = 64, WM = 2, WN = 2, CH = 8, TM = 4, TN = 4;
+    constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
+    static_assert(EPI != EPI_SILU || BN / WN == 64, "SiLU epilogue pairs columns inside a 64-wide wave slice");
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WN, wn = wave % WN;
+    const uint32_t tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
+    uint32_t mt_i, nt_i;
+    {
+        const uint32_t id = blockIdx.x;
+        if (tiles_n % 8 == 0) {
+            const uint32_t xcd = id & 7, slot = id >> 3;
+            nt_i = (slot / tiles_m) * 8 + xcd;
+            mt_i = slot % tiles_m;
         } else {
+            nt_i = id / tiles_m;
+            mt_i = id % tiles_m;
+        }
+    }
+    const uint32_t m0 = mt_i * BM, n0 = nt_i * BN, batch = blockIdx.y;
+    if (p.causal == 1 && n0 > p.causal_pos0 + m0 + BM - 1) return;
+    const GLOBAL_AS uint8_t *Ab = (const GLOBAL_AS uint8_t *)(p.A + (uint64_t)batch * p.a_bs);
+    const uint32_t seg = n0 < p.seg_end[0] ? 0u : (n0 < p.seg_end[1] ? 1u : 2u);
+    const uint32_t nrow0 = n0 - (seg == 0 ? 0u : p.seg_end[seg - 1]);
+    const GLOBAL_AS uint8_t *Bb = (const GLOBAL_AS uint8_t *)(p.B[seg] + (uint64_t)(batch / p.b_div) * p.b_bs);
+    const GLOBAL_AS uint8_t *Bg = (const GLOBAL_AS uint8_t *)p.B[0], *Bu = (const GLOBAL_AS uint8_t *)p.B[1];
+
+    // per-lane source rows: instruction i of this wave covers LDS rows (i*4 + wave)*8 .. +7, lane = (row & 7) * 8 + c'
+    const uint32_t lrow = lane >> 3, lc = lane & 7;
+    const GLOBAL_AS uint8_t *asrc[4], *bsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t row = (i * 4 + wave) * 8 + lrow;
+        const uint32_t chunk = lc ^ (row & 7);
+        asrc[i] = Ab + ((uint64_t)min(m0 + row, p.M - 1) * p.lda + chunk * 8) * 2;
+        if constexpr (EPI == EPI_SILU) {
+            const uint32_t sl = row >> 6, cc = row & 63, out = n0 / 2 + sl * 32 + (cc & 31);
+            bsrc[i] = (cc < 32 ? Bg : Bu) + ((uint64_t)out * p.ldb + chunk * 8) * 2;
+        } else {
+            bsrc[i] = Bb + ((uint64_t)(nrow0 + row) * p.ldb + chunk * 8) * 2;
+        }
+    }
+    auto issue_tile = [&](uint32_t kt, uint32_t stage) {
+        const uint32_t koff = kt * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            lds_u8 *da = (lds_u8 *)(lds + stage * STAGE + (i * 4 + wave) * 1024);
+            lds_u8 *db = (lds_u8 *)(lds + stage * STAGE + A_BYTES + (i * 4 + wave) * 1024);
+            __builtin_amdgcn_global_load_lds(asrc[i] + koff, da, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(bsrc[i] + koff, db, 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint32_t KT = p.K / BK;
+    if (p.causal == 2) KT = min(KT, (p.causal_pos0 + m0 + BM + BK - 1) / BK);
+#pragma unroll
+    for (int s = 0; s < NST - 1; s++) issue_tile(min((uint32_t)s, KT - 1), s);
+
+    uint32_t cur = 0, fill = NST - 1;  // stage being multiplied, stage being refilled
+    for (uint32_t kt = 0; kt < KT; kt++) {
+        if constexpr (NST == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue_tile(min(kt + NST - 1, KT - 1), fill);
+        const uint8_t *la = lds + cur * STAGE, *lb = la + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ks++) {
+            const uint32_t chunk = ks * 4 + (lane >> 4);
+            f16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) af[i] = *reinterpret_cast<const f16x8 *>(la + lds_off<CH>(wm * 64 + i * 16 + (lane & 15), chunk));
+#pragma unroll
+            for (int j = 0; j < TN; j++) bf[j] = *reinterpret_cast<const f16x8 *>(lb + lds_off<CH>(wn * 64 + j * 16 + (lane & 15), chunk));
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
-                for (int j = 0; j < TN; j++) acc[i][j] *= p.alpha;
+                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const uint32_t row = rbase + i * 16 + r, col = n0 + cbase + j * 16;
-                    if (row < p.M) Cb[(uint64_t)row * p.ldc + col] = acc[i][j][r];
-                }
+        cur = cur + 1 == NST ? 0 : cur + 1;
+        fill = fill + 1 == NST ? 0 : fill + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus DMAs of the last iterations must not outlive the workgroup's LDS
+    gemm_store<BM, BN, WM, WN, EPI, TM, TN>(acc, p, m0, n0, wm, wn, lane, batch);
+}
+
+template <int EPI, int NST>
+static hipError_t gemm_launch_glds(const GemmParams &p, uint32_t batch, hipStream_t s)
+{
+    constexpr int LDS = NST * (128 + 128) * 64 * 2;
+    auto kern = k_gemm_f16_glds<EPI, NST>;
+    static bool attr_set = false;
+    if (LDS > 64 * 1024 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const uint32_t tiles = ((p.M + 127) / 128) * (p.N / 128);
+    hipLaunchKernelGGL(kern, dim3(tiles, batch, 1), dim3(256), LDS, s, p);
+    return hipGetLastError();
 }
 
 template <int BM, int BN, int WM, int WN, int BK, int EPI, int KS = 1, int RING = 3>
@@ -306,8 +437,18 @@ static hipError_t gemm_launch(const GemmParams &p, uint32_t batch, hipStream_t s
 }
 
 template <int EPI>
-static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, hipStream_t s)
+static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int variant, hipStream_t s)
 {
+    if (variant) {  // explicit configuration (tests, tools)
+        if (variant >= 2 && p.N % 128 != 0) return hipErrorInvalidValue;
+        switch (variant) {
+            case 1: return gemm_launch<128, 64, 4, 1, 64, EPI>(p, batch, s);
+            case 2: return gemm_launch<128, 128, 2, 2, 64, EPI>(p, batch, s);
+            case 3: return gemm_launch_glds<EPI, 2>(p, batch, s);
+            case 4: return gemm_launch_glds<EPI, 3>(p, batch, s);
+        }
+        return hipErrorInvalidValue;
+    }
     static const int env_big = getenv("NFAI_GEMM_BIG") ? atoi(getenv("NFAI_GEMM_BIG")) : 1;
     const uint64_t big_tiles = (uint64_t)((p.M + 127) / 128) * (p.N / 128) * batch;
     if constexpr (EPI == EPI_F32) {
@@ -334,7 +475,15 @@ static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, hipStr
             }
         }
     }
-    if (env_big && p.N % 128 == 0 && big_tiles >= (uint64_t)n_cu * 3 / 2) return gemm_launch<128, 128, 2, 2, 64, EPI>(p, batch, s);
+    // wide N: direct-to-LDS staging with 2 stages (64 KB: two workgroups per CU).  Measured end to end (3B, T = 512, three
+    // runs each): 7.20 ms against 7.37 ms for the register-staged 128 x 128 kernel and 8.0 ms for 3 stages (96 KB: one
+    // workgroup per CU — occupancy beats prefetch depth here).  NFAI_GEMM_GLDS=0 selects the register-staged kernel.
+    static const int env_glds = getenv("NFAI_GEMM_GLDS") ? atoi(getenv("NFAI_GEMM_GLDS")) : 2;
+    if (env_big && p.N % 128 == 0 && big_tiles >= (uint64_t)n_cu * 3 / 2) {
+        if (env_glds == 3 && p.ksplit == 1) return gemm_launch_glds<EPI, 3>(p, batch, s);
+        if (env_glds == 2 && p.ksplit == 1) return gemm_launch_glds<EPI, 2>(p, batch, s);
+        return gemm_launch<128, 128, 2, 2, 64, EPI>(p, batch, s);
+    }
     // at most ~one workgroup per CU: nothing else hides latency, so twice the bytes in flight and half the barriers
     static const int env_bk = getenv("NFAI_GEMM_BK128") ? atoi(getenv("NFAI_GEMM_BK128")) : 0;  // measured: 3 % slower than BK = 64
     const uint64_t small_tiles = (uint64_t)((p.M + 127) / 128) * (p.N / 64) * batch;
@@ -374,15 +523,15 @@ hipError_t launch_gemm_f16(const GemmArgs &a, hipStream_t s)
     if (a.epi == EPI_SILU) {
         // N counts gate + up columns; the two segments must be equally long and the output is [M][N/2] fp16
         if (!a.B1 || a.n0 * 2 != a.N || a.R || batch != 1) return hipErrorInvalidValue;
-        return gemm_pick<EPI_SILU>(p, batch, n_cu, s);
+        return gemm_pick<EPI_SILU>(p, batch, n_cu, a.variant, s);
     }
     // a segment boundary inside a 128-wide tile is not supported by the wide configuration: fall back
     if ((p.seg_end[0] | p.seg_end[1]) % 128) {
         if (a.epi == EPI_F16) return a.R ? hipErrorInvalidValue : gemm_launch<128, 64, 4, 1, 64, EPI_F16>(p, batch, s);
         return gemm_launch<128, 64, 4, 1, 64, EPI_F32>(p, batch, s);
     }
-    if (a.epi == EPI_F16) return a.R ? hipErrorInvalidValue : gemm_pick<EPI_F16>(p, batch, n_cu, s);
-    return gemm_pick<EPI_F32>(p, batch, n_cu, s);
+    if (a.epi == EPI_F16) return a.R ? hipErrorInvalidValue : gemm_pick<EPI_F16>(p, batch, n_cu, a.variant, s);
+    return gemm_pick<EPI_F32>(p, batch, n_cu, a.variant, s);
 }
 
 // fp32 rows -> fp16 (the attention output on its way into the Wo GEMM)

@@ -360,3 +360,30 @@ def test_error_paths(mgr):
     with pytest.raises(NfaiHipError) as e:
         mgr.UploadWeight(_lib.Q4_K, np.zeros(100, np.uint8), 1, 100)  # K-quants need K % 256 == 0
     assert e.value.code == _lib.ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4], ids=["auto", "128x64", "128x128", "glds2", "glds3"])
+@pytest.mark.parametrize("M,N,K,res", [(512, 1024, 512, True), (200, 256, 192, False), (128, 384, 3072, True)])
+def test_gemm_f16_variants(mgr, variant, M, N, K, res):
+    """The prefill GEMM (MatrixMultiplyShader with inputRowCount = M, which the reference never exercises) in every tile /
+    staging configuration against fp64 NumPy on the same fp16 operands: fp32 accumulation, so the error is summation-order
+    noise: |d| <= 2e-6 * sqrt(K) * |A||W| scale + 1e-6.  Covers the direct-to-LDS kernels, ragged M and the residual."""
+    from nfai_amd._lib import call
+    from nfai_amd.hip import ShaderProperty
+    r = np.random.Generator(np.random.PCG64(100 * variant + M))
+    A = r.standard_normal((M, K)).astype(np.float16)
+    W = (0.05 * r.standard_normal((N, K))).astype(np.float16)
+    R = r.standard_normal((M, N)).astype(np.float32) if res else None
+    pa, pw = ShaderProperty(mgr, M * K, np.float16), ShaderProperty(mgr, N * K, np.float16)
+    pc = ShaderProperty(mgr, M * N, np.float32)
+    pa.SetValue(A.ravel()); pw.SetValue(W.ravel())
+    pr = None
+    if res:
+        pr = ShaderProperty(mgr, M * N, np.float32)
+        pr.SetValue(R.ravel())
+    call("nfai_hip_gemm_f16", mgr.handle, pa.handle, pw.handle, pr.handle if res else 0, pc.handle, M, N, K, variant)
+    got = pc.GetValue().reshape(M, N)
+    want = A.astype(np.float64) @ W.astype(np.float64).T + (R.astype(np.float64) if res else 0.0)
+    scale = float(np.abs(A.astype(np.float64)).mean() * np.abs(W.astype(np.float64)).mean() * K)
+    assert np.abs(got - want).max() <= 2e-6 * np.sqrt(K) * scale + 1e-5, np.abs(got - want).max()
