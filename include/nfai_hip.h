@@ -148,7 +148,8 @@ int32_t nfai_hip_attn_decode(nfai_ctx_t ctx, nfai_buf_t q, nfai_buf_t kcache, nf
 /* Batched form of MatrixMultiplyShader (inputRowCount = M > 1, which the reference never uses: MatrixMultiplyShader.cs:31-47
  * takes the row count, TransformerBlock.cs:47-101 always passes 1): C[M][N] fp32 (+ residual R, may be 0) = A[M][K] * W[N][K]^T
  * with fp16 operands on the matrix cores — the GEMM of the MFMA prefill, exposed for tests and tools.  variant: 0 = chosen
- * from the shape, 1 = 128x64 tiles, 2 = 128x128 tiles, 3 / 4 = direct-to-LDS staging with 2 / 3 stages (N %% 128 == 0). */
+ * from the shape, 1 = 128x64 tiles, 2 = 128x128 tiles, 3 / 4 = direct-to-LDS staging of 128x128 tiles with 2 / 3 stages (N %% 128 == 0),
+ * 5 / 6 / 7 = direct-to-LDS staging of 128x64 tiles with 2 / 3 / 4 stages. */
 int32_t nfai_hip_gemm_f16(nfai_ctx_t ctx, nfai_buf_t A_f16, nfai_buf_t W_f16, nfai_buf_t R, nfai_buf_t C, uint32_t M, uint32_t N,
                           uint32_t K, int32_t variant);
 int32_t nfai_hip_gemv_fused(nfai_ctx_t ctx, nfai_buf_t W, int32_t w_type, nfai_buf_t x, nfai_buf_t gamma,

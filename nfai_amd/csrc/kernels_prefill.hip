@@ -295,21 +295,33 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void k_gemm_f16(const GemmParams p
     gemm_store<BM, BN, WM, WN, EPI, TM, TN>(acc, p, m0, n0, wm, wn, lane, batch);
 }
 
-// ---- direct-to-LDS variant (128 x 128 x 64 tile, 2 x 2 waves of 64 x 64) ---------------------------------------------
+// ---- direct-to-LDS variants (128 x 128 x 64 tiles with 2 x 2 waves of 64 x 64; 128 x 64 x 64 with 4 x 1 waves) --------------
 // Operands go global -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write pass); NST LDS stages, tile kt + NST - 1
 // is requested while tile kt is multiplied.  One raw s_barrier per K tile:
-//     s_waitcnt vmcnt(8 (NST - 2))   my share of tile kt has landed (tiles kt+1 .. kt+NST-2 may still be in flight)
+//     s_waitcnt vmcnt(G (NST - 2))   my share of tile kt has landed (G = LDS-DMA instructions per wave and tile: 8 or 6) (tiles kt+1 .. kt+NST-2 may still be in flight)
 //     s_barrier                      everybody's share has; everybody is past the MFMAs of tile kt-1
-//     8 x global_load_lds            tile kt+NST-1 -> the stage tile kt-1 just vacated (past the end: the last tile again,
+//     G x global_load_lds            tile kt+NST-1 -> the stage tile kt-1 just vacated (past the end: the last tile again,
 //                                    into a stage nobody reads any more — the counts stay uniform, nothing is conditional)
 //     MFMAs on tile kt
 // An LDS-DMA instruction writes lane-linear (wave-uniform base + lane * 16 B): the XOR swizzle of the fragment reads is
 // applied to the SOURCE address instead (LDS slot (row, c') receives global chunk c' ^ (row & 7)).  Plain __syncthreads()
 // would drain the DMAs (its fence waits vmcnt(0)), hence the raw barrier + counted waits (MI355X guide, §5).
-template <int EPI, int NST>
+template <int N> __device__ __forceinline__ void wait_vmcnt()
+{
+    static_assert(N == 0 || N == 6 || N == 8 || N == 12 || N == 16, "add the literal");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+}
+
+template <int BM, int BN, int WM, int WN, int EPI, int NST>
 __global__ __launch_bounds__(256) void k_gemm_f16_glds(const GemmParams p)
 {
-    constexpr int BM = 128, BN = 128, BK = 64, WM = 2, WN = 2, CH = 8, TM = 4, TN = 4;
+    static_assert(WM * WN == 4, "four waves");
+    constexpr int BK = 64, CH = 8, TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int AG = BM / 8 / 4, BG = BN / 8 / 4;  // 8-row groups (one LDS-DMA instruction each) per wave
     constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
     static_assert(EPI != EPI_SILU || BN / WN == 64, "SiLU epilogue pairs columns inside a 64-wide wave slice");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -340,12 +352,17 @@ __global__ __launch_bounds__(256) void k_gemm_f16_glds(const GemmParams p)
 
     // per-lane source rows: instruction i of this wave covers LDS rows (i*4 + wave)*8 .. +7, lane = (row & 7) * 8 + c'
     const uint32_t lrow = lane >> 3, lc = lane & 7;
-    const GLOBAL_AS uint8_t *asrc[4], *bsrc[4];
+    static_assert(AG <= 4 && BG <= 4, "source pointer arrays");
+    const GLOBAL_AS uint8_t *asrc[4], *bsrc[4];  // fixed bounds: with [AG] / [BG] the host pass of hipcc 7.2 silently drops the kernel's definition
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < AG; i++) {
+        const uint32_t row = (i * 4 + wave) * 8 + lrow;
+        asrc[i] = Ab + ((uint64_t)min(m0 + row, p.M - 1) * p.lda + (lc ^ (row & 7)) * 8) * 2;
+    }
+#pragma unroll
+    for (int i = 0; i < BG; i++) {
         const uint32_t row = (i * 4 + wave) * 8 + lrow;
         const uint32_t chunk = lc ^ (row & 7);
-        asrc[i] = Ab + ((uint64_t)min(m0 + row, p.M - 1) * p.lda + chunk * 8) * 2;
         if constexpr (EPI == EPI_SILU) {
             const uint32_t sl = row >> 6, cc = row & 63, out = n0 / 2 + sl * 32 + (cc & 31);
             bsrc[i] = (cc < 32 ? Bg : Bu) + ((uint64_t)out * p.ldb + chunk * 8) * 2;
@@ -356,10 +373,13 @@ __global__ __launch_bounds__(256) void k_gemm_f16_glds(const GemmParams p)
     auto issue_tile = [&](uint32_t kt, uint32_t stage) {
         const uint32_t koff = kt * (BK * 2);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < AG; i++) {
             lds_u8 *da = (lds_u8 *)(lds + stage * STAGE + (i * 4 + wave) * 1024);
-            lds_u8 *db = (lds_u8 *)(lds + stage * STAGE + A_BYTES + (i * 4 + wave) * 1024);
             __builtin_amdgcn_global_load_lds(asrc[i] + koff, da, 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BG; i++) {
+            lds_u8 *db = (lds_u8 *)(lds + stage * STAGE + A_BYTES + (i * 4 + wave) * 1024);
             __builtin_amdgcn_global_load_lds(bsrc[i] + koff, db, 16, 0, 0);
         }
     };
@@ -377,8 +397,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16_glds(const GemmParams p)
 
     uint32_t cur = 0, fill = NST - 1;  // stage being multiplied, stage being refilled
     for (uint32_t kt = 0; kt < KT; kt++) {
-        if constexpr (NST == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_vmcnt<(AG + BG) * (NST - 2)>();
         __builtin_amdgcn_s_barrier();
         issue_tile(min(kt + NST - 1, KT - 1), fill);
         const uint8_t *la = lds + cur * STAGE, *lb = la + A_BYTES;
@@ -387,9 +406,9 @@ __global__ __launch_bounds__(256) void k_gemm_f16_glds(const GemmParams p)
             const uint32_t chunk = ks * 4 + (lane >> 4);
             f16x8 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; i++) af[i] = *reinterpret_cast<const f16x8 *>(la + lds_off<CH>(wm * 64 + i * 16 + (lane & 15), chunk));
+            for (int i = 0; i < TM; i++) af[i] = *reinterpret_cast<const f16x8 *>(la + lds_off<CH>(wm * (BM / WM) + i * 16 + (lane & 15), chunk));
 #pragma unroll
-            for (int j = 0; j < TN; j++) bf[j] = *reinterpret_cast<const f16x8 *>(lb + lds_off<CH>(wn * 64 + j * 16 + (lane & 15), chunk));
+            for (int j = 0; j < TN; j++) bf[j] = *reinterpret_cast<const f16x8 *>(lb + lds_off<CH>(wn * (BN / WN) + j * 16 + (lane & 15), chunk));
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -402,18 +421,18 @@ __global__ __launch_bounds__(256) void k_gemm_f16_glds(const GemmParams p)
     gemm_store<BM, BN, WM, WN, EPI, TM, TN>(acc, p, m0, n0, wm, wn, lane, batch);
 }
 
-template <int EPI, int NST>
+template <int BM, int BN, int WM, int WN, int EPI, int NST>
 static hipError_t gemm_launch_glds(const GemmParams &p, uint32_t batch, hipStream_t s)
 {
-    constexpr int LDS = NST * (128 + 128) * 64 * 2;
-    auto kern = k_gemm_f16_glds<EPI, NST>;
+    constexpr int LDS = NST * (BM + BN) * 64 * 2;
+    auto kern = k_gemm_f16_glds<BM, BN, WM, WN, EPI, NST>;
     static bool attr_set = false;
     if (LDS > 64 * 1024 && !attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const uint32_t tiles = ((p.M + 127) / 128) * (p.N / 128);
+    const uint32_t tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
     hipLaunchKernelGGL(kern, dim3(tiles, batch, 1), dim3(256), LDS, s, p);
     return hipGetLastError();
 }
@@ -440,12 +459,15 @@ template <int EPI>
 static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int variant, hipStream_t s)
 {
     if (variant) {  // explicit configuration (tests, tools)
-        if (variant >= 2 && p.N % 128 != 0) return hipErrorInvalidValue;
+        if (variant >= 2 && variant <= 4 && p.N % 128 != 0) return hipErrorInvalidValue;
         switch (variant) {
             case 1: return gemm_launch<128, 64, 4, 1, 64, EPI>(p, batch, s);
             case 2: return gemm_launch<128, 128, 2, 2, 64, EPI>(p, batch, s);
-            case 3: return gemm_launch_glds<EPI, 2>(p, batch, s);
-            case 4: return gemm_launch_glds<EPI, 3>(p, batch, s);
+            case 3: return gemm_launch_glds<128, 128, 2, 2, EPI, 2>(p, batch, s);
+            case 4: return gemm_launch_glds<128, 128, 2, 2, EPI, 3>(p, batch, s);
+            case 5: return gemm_launch_glds<128, 64, 4, 1, EPI, 2>(p, batch, s);
+            case 6: return gemm_launch_glds<128, 64, 4, 1, EPI, 3>(p, batch, s);
+            case 7: return gemm_launch_glds<128, 64, 4, 1, EPI, 4>(p, batch, s);
         }
         return hipErrorInvalidValue;
     }
@@ -480,8 +502,8 @@ static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int va
     // workgroup per CU — occupancy beats prefetch depth here).  NFAI_GEMM_GLDS=0 selects the register-staged kernel.
     static const int env_glds = getenv("NFAI_GEMM_GLDS") ? atoi(getenv("NFAI_GEMM_GLDS")) : 2;
     if (env_big && p.N % 128 == 0 && big_tiles >= (uint64_t)n_cu * 3 / 2) {
-        if (env_glds == 3 && p.ksplit == 1) return gemm_launch_glds<EPI, 3>(p, batch, s);
-        if (env_glds == 2 && p.ksplit == 1) return gemm_launch_glds<EPI, 2>(p, batch, s);
+        if (env_glds == 3 && p.ksplit == 1) return gemm_launch_glds<128, 128, 2, 2, EPI, 3>(p, batch, s);
+        if (env_glds == 2 && p.ksplit == 1) return gemm_launch_glds<128, 128, 2, 2, EPI, 2>(p, batch, s);
         return gemm_launch<128, 128, 2, 2, 64, EPI>(p, batch, s);
     }
     // at most ~one workgroup per CU: nothing else hides latency, so twice the bytes in flight and half the barriers
@@ -492,6 +514,12 @@ static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int va
     if (env_ks && small_tiles <= (uint64_t)n_cu * 3 / 2) return gemm_launch<128, 64, 4, 1, 64, EPI, 2>(p, batch, s);
     static const int env_m64 = getenv("NFAI_GEMM_M64") ? atoi(getenv("NFAI_GEMM_M64")) : 0;  // measured: 15 % slower than 128 x 64 on 192 workgroups
     if (env_m64 && small_tiles < n_cu && p.M > 64) return gemm_launch<64, 64, 2, 1, 64, EPI>(p, batch, s);  // fewer tiles than CUs: halve the M tile
+    // narrow N (192-320 workgroups of 128 x 64): direct-to-LDS with 3 stages (72 KB).  Measured end to end, three runs
+    // each: 7.06 ms against 7.18 ms register-staged; 2 stages 8.27 ms, 4 stages 7.42 ms.  0 = register staging.
+    static const int env_glds_n = getenv("NFAI_GEMM_GLDS_NARROW") ? atoi(getenv("NFAI_GEMM_GLDS_NARROW")) : 3;
+    if (env_glds_n == 2 && p.ksplit == 1) return gemm_launch_glds<128, 64, 4, 1, EPI, 2>(p, batch, s);
+    if (env_glds_n == 3 && p.ksplit == 1) return gemm_launch_glds<128, 64, 4, 1, EPI, 3>(p, batch, s);
+    if (env_glds_n == 4 && p.ksplit == 1) return gemm_launch_glds<128, 64, 4, 1, EPI, 4>(p, batch, s);
     static const int env_ring = getenv("NFAI_GEMM_RING") ? atoi(getenv("NFAI_GEMM_RING")) : 3;  // measured: 5 is 5 % slower
     if (env_ring == 5 && small_tiles <= (uint64_t)n_cu * 3 / 2) return gemm_launch<128, 64, 4, 1, 64, EPI, 1, 5>(p, batch, s);
     return gemm_launch<128, 64, 4, 1, 64, EPI>(p, batch, s);
