@@ -316,12 +316,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
     else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int NST>
+// PIPE: the fragments of k-step s+1 are read from LDS while the MFMAs of step s run (double-buffered registers, issue order
+// pinned with sched_group_barrier).  Left alone hipcc reads a whole step, waits lgkmcnt(0) and then issues its MFMAs: with one
+// wave per SIMD (the narrow GEMMs: one workgroup per CU) every step then exposes a full LDS latency.
+template <int BM, int BN, int WM, int WN, int EPI, int NST, int BK = 64, bool PIPE = false>
 __global__ __launch_bounds__(256) void k_gemm_f16_glds(const GemmParams p)
 {
     static_assert(WM * WN == 4, "four waves");
-    constexpr int BK = 64, CH = 8, TM = BM / WM / 16, TN = BN / WN / 16;
-    constexpr int AG = BM / 8 / 4, BG = BN / 8 / 4;  // 8-row groups (one LDS-DMA instruction each) per wave
+    constexpr int CH = BK / 8, RPI = 64 / CH, TM = BM / WM / 16, TN = BN / WN / 16;  // RPI = tile rows per LDS-DMA instruction
+    constexpr int AG = BM / RPI / 4, BG = BN / RPI / 4;  // LDS-DMA instructions per wave and tile
     constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
     static_assert(EPI != EPI_SILU || BN / WN == 64, "SiLU epilogue pairs columns inside a 64-wide wave slice");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -350,19 +353,19 @@ __global__ __launch_bounds__(256) void k_gemm_f16_glds(const GemmParams p)
     const GLOBAL_AS uint8_t *Bb = (const GLOBAL_AS uint8_t *)(p.B[seg] + (uint64_t)(batch / p.b_div) * p.b_bs);
     const GLOBAL_AS uint8_t *Bg = (const GLOBAL_AS uint8_t *)p.B[0], *Bu = (const GLOBAL_AS uint8_t *)p.B[1];
 
-    // per-lane source rows: instruction i of this wave covers LDS rows (i*4 + wave)*8 .. +7, lane = (row & 7) * 8 + c'
-    const uint32_t lrow = lane >> 3, lc = lane & 7;
-    static_assert(AG <= 4 && BG <= 4, "source pointer arrays");
-    const GLOBAL_AS uint8_t *asrc[4], *bsrc[4];  // fixed bounds: with [AG] / [BG] the host pass of hipcc 7.2 silently drops the kernel's definition
+    // per-lane source rows: instruction i of this wave covers LDS rows (i*4 + wave)*RPI .. +RPI-1, lane = (row % RPI) * CH + c'
+    const uint32_t lrow = lane / CH, lc = lane % CH;
+    static_assert(AG <= 8 && BG <= 8, "source pointer arrays");
+    const GLOBAL_AS uint8_t *asrc[8], *bsrc[8];  // fixed bounds: with [AG] / [BG] the host pass of hipcc 7.2 silently drops the kernel's definition
 #pragma unroll
     for (int i = 0; i < AG; i++) {
-        const uint32_t row = (i * 4 + wave) * 8 + lrow;
-        asrc[i] = Ab + ((uint64_t)min(m0 + row, p.M - 1) * p.lda + (lc ^ (row & 7)) * 8) * 2;
+        const uint32_t row = (i * 4 + wave) * RPI + lrow;
+        asrc[i] = Ab + ((uint64_t)min(m0 + row, p.M - 1) * p.lda + (lc ^ (row & (CH - 1))) * 8) * 2;
     }
 #pragma unroll
     for (int i = 0; i < BG; i++) {
-        const uint32_t row = (i * 4 + wave) * 8 + lrow;
-        const uint32_t chunk = lc ^ (row & 7);
+        const uint32_t row = (i * 4 + wave) * RPI + lrow;
+        const uint32_t chunk = lc ^ (row & (CH - 1));
         if constexpr (EPI == EPI_SILU) {
             const uint32_t sl = row >> 6, cc = row & 63, out = n0 / 2 + sl * 32 + (cc & 31);
             bsrc[i] = (cc < 32 ? Bg : Bu) + ((uint64_t)out * p.ldb + chunk * 8) * 2;
@@ -401,18 +404,51 @@ __global__ __launch_bounds__(256) void k_gemm_f16_glds(const GemmParams p)
         __builtin_amdgcn_s_barrier();
         issue_tile(min(kt + NST - 1, KT - 1), fill);
         const uint8_t *la = lds + cur * STAGE, *lb = la + A_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < BK / 32; ks++) {
+        constexpr int KSTEPS = BK / 32;
+        auto load_frags = [&](int ks, f16x8 (&a)[TM], f16x8 (&b)[TN]) {
             const uint32_t chunk = ks * 4 + (lane >> 4);
-            f16x8 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; i++) af[i] = *reinterpret_cast<const f16x8 *>(la + lds_off<CH>(wm * (BM / WM) + i * 16 + (lane & 15), chunk));
+            for (int i = 0; i < TM; i++) a[i] = *reinterpret_cast<const f16x8 *>(la + lds_off<CH>(wm * (BM / WM) + i * 16 + (lane & 15), chunk));
 #pragma unroll
-            for (int j = 0; j < TN; j++) bf[j] = *reinterpret_cast<const f16x8 *>(lb + lds_off<CH>(wn * (BN / WN) + j * 16 + (lane & 15), chunk));
+            for (int j = 0; j < TN; j++) b[j] = *reinterpret_cast<const f16x8 *>(lb + lds_off<CH>(wn * (BN / WN) + j * 16 + (lane & 15), chunk));
+        };
+        if constexpr (PIPE) {
+            f16x8 af[2][TM], bf[2][TN];
+            load_frags(0, af[0], bf[0]);
 #pragma unroll
-            for (int i = 0; i < TM; i++)
+            for (int ks = 0; ks < KSTEPS; ks++) {
+                if (ks + 1 < KSTEPS) load_frags(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
 #pragma unroll
-                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+            }
+            // issue order: reads of step 0; then, per step, one read of the next step behind every MFMA until it is complete
+            static_assert(TM * TN >= TM + TN, "more MFMAs than fragment reads per step");
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ks++) {
+                if (ks + 1 < KSTEPS) {
+#pragma unroll
+                    for (int q = 0; q < TM + TN; q++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ks++) {
+                f16x8 af[TM], bf[TN];
+                load_frags(ks, af, bf);
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
         }
         cur = cur + 1 == NST ? 0 : cur + 1;
         fill = fill + 1 == NST ? 0 : fill + 1;
@@ -421,11 +457,12 @@ __global__ __launch_bounds__(256) void k_gemm_f16_glds(const GemmParams p)
     gemm_store<BM, BN, WM, WN, EPI, TM, TN>(acc, p, m0, n0, wm, wn, lane, batch);
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int NST>
+template <int BM, int BN, int WM, int WN, int EPI, int NST, int BK = 64, bool PIPE = false>
 static hipError_t gemm_launch_glds(const GemmParams &p, uint32_t batch, hipStream_t s)
 {
-    constexpr int LDS = NST * (BM + BN) * 64 * 2;
-    auto kern = k_gemm_f16_glds<BM, BN, WM, WN, EPI, NST>;
+    constexpr int LDS = NST * (BM + BN) * BK * 2;
+    if (p.K % BK) return hipErrorInvalidValue;
+    auto kern = k_gemm_f16_glds<BM, BN, WM, WN, EPI, NST, BK, PIPE>;
     static bool attr_set = false;
     if (LDS > 64 * 1024 && !attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -459,7 +496,7 @@ template <int EPI>
 static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int variant, hipStream_t s)
 {
     if (variant) {  // explicit configuration (tests, tools)
-        if (variant >= 2 && variant <= 4 && p.N % 128 != 0) return hipErrorInvalidValue;
+        if (((variant >= 2 && variant <= 4) || variant == 11) && p.N % 128 != 0) return hipErrorInvalidValue;
         switch (variant) {
             case 1: return gemm_launch<128, 64, 4, 1, 64, EPI>(p, batch, s);
             case 2: return gemm_launch<128, 128, 2, 2, 64, EPI>(p, batch, s);
@@ -468,6 +505,10 @@ static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int va
             case 5: return gemm_launch_glds<128, 64, 4, 1, EPI, 2>(p, batch, s);
             case 6: return gemm_launch_glds<128, 64, 4, 1, EPI, 3>(p, batch, s);
             case 7: return gemm_launch_glds<128, 64, 4, 1, EPI, 4>(p, batch, s);
+            case 8: return gemm_launch_glds<128, 64, 4, 1, EPI, 3, 64, true>(p, batch, s);    // + pipelined fragment reads
+            case 9: return gemm_launch_glds<128, 64, 4, 1, EPI, 3, 128, true>(p, batch, s);   // BK 128, 3 stages (144 KB)
+            case 10: return gemm_launch_glds<128, 64, 4, 1, EPI, 2, 128, true>(p, batch, s);  // BK 128, 2 stages
+            case 11: return gemm_launch_glds<128, 128, 2, 2, EPI, 2, 64, true>(p, batch, s);
         }
         return hipErrorInvalidValue;
     }

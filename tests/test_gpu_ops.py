@@ -363,8 +363,9 @@ def test_error_paths(mgr):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7], ids=["auto", "128x64", "128x128", "glds2", "glds3", "glds-n2", "glds-n3", "glds-n4"])
-@pytest.mark.parametrize("M,N,K,res", [(512, 1024, 512, True), (200, 256, 192, False), (128, 384, 3072, True)])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11],
+                         ids=["auto", "128x64", "128x128", "glds2", "glds3", "glds-n2", "glds-n3", "glds-n4", "glds-n3-pipe", "glds-n3-bk128", "glds-n2-bk128", "glds2-pipe"])
+@pytest.mark.parametrize("M,N,K,res", [(512, 1024, 512, True), (200, 256, 384, False), (128, 384, 3072, True)])
 def test_gemm_f16_variants(mgr, variant, M, N, K, res):
     """The prefill GEMM (MatrixMultiplyShader with inputRowCount = M, which the reference never exercises) in every tile /
     staging configuration against fp64 NumPy on the same fp16 operands: fp32 accumulation, so the error is summation-order

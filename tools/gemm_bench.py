@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nfai_amd._lib import call  # noqa: E402
 from nfai_amd.hip import HipBufferManager, ShaderProperty  # noqa: E402
 
-NAMES = {0: "auto", 1: "128x64 reg", 2: "128x128 reg", 3: "128x128 glds2", 4: "128x128 glds3", 5: "128x64 glds2", 6: "128x64 glds3", 7: "128x64 glds4"}
+NAMES = {0: "auto", 1: "128x64 reg", 2: "128x128 reg", 3: "128x128 glds2", 4: "128x128 glds3", 5: "128x64 glds2", 6: "128x64 glds3", 7: "128x64 glds4", 8: "128x64 glds3 pipe", 9: "128x64 glds3 bk128 pipe", 10: "128x64 glds2 bk128 pipe", 11: "128x128 glds2 pipe"}
 
 
 def main():
@@ -23,7 +23,7 @@ def main():
         pa.SetValue(r.standard_normal(T * K).astype(np.float16))
         pw.SetValue((0.02 * r.standard_normal(N * K)).astype(np.float16))
         line = f"M={T} N={N} K={K}:"
-        for v in (1, 5, 6, 7, 2, 3, 4, 0, 1):
+        for v in (1, 6, 8, 9, 10, 3, 11, 0, 6):
             for _ in range(3):
                 call("nfai_hip_gemm_f16", mgr.handle, pa.handle, pw.handle, 0, pc.handle, T, N, K, v)
             mgr.Synchronize()
