@@ -184,7 +184,7 @@ def run_bench_pipeline(args):
     ranges = partition_layers(dims.L, world, layer_bytes, head_bytes)
     lb, le = ranges[rank]
     first, last = rank == 0, rank == world - 1
-    weights = B.gen_weights_hbm(torch, dims, (lb, le), first, last, seed=1234 + rank)
+    weights = B.gen_weights_hbm(torch, dims, (lb, le), first, last, seed=1234 + rank, quant=args.quant)
     stream = torch.cuda.Stream()
     C = args.context + args.warmup + args.steps
     with torch.cuda.stream(stream):
@@ -222,7 +222,7 @@ def run_bench_pipeline(args):
             "value": n_tok / dt, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{dims.name} fp16-GGUF weights, fp32 activations + {'fp16' if args.kv_f16 else 'fp32'} KV, "
+            "config": {"workload": f"{dims.name} {'fp16-GGUF' if args.quant == 'f16' else 'Q4_K_M-GGUF'} weights, fp32 activations + {'fp16' if args.kv_f16 else 'fp32'} KV, "
                                    f"{world} independent batch-1 greedy sequences in flight over a {world}-stage layer pipeline, "
                                    f"{args.steps} tokens each after a {args.context}-token context",
                        "parallelism": f"pp{world}", "layer_ranges": ranges, "kv_capacity": C},
