@@ -237,6 +237,9 @@ def run_single(args):
         if args.model == "llama-3.2-3b" and args.quant == "f16":
             pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))
             traffic = pmc["kernels"]["nfai::k_gemv<1, 3, 2, 3, false, true>"]["hbm_bytes_per_launch"]
+        elif args.model == "llama-3.2-3b":
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic_q4km.json")))
+            traffic = pmc["kernels"]["nfai::k_gemv_kqt<112, 3, 1, true, 0>"]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         traffic = None
     gu_eager_ms = prof["gateup"][0] / max(1, prof["gateup"][1]) if prof else float("nan")
