@@ -122,24 +122,39 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
     const float scale = 1.0f / sqrtf((float)D);  // …ScoreCalculationShader.cs:93
 
     // ---- phase 1: scores of the slice -> LDS ------------------------------------------------
-    for (uint32_t i = grp;; i += NGRP * PF) {
+    // A slice of the benchmark's context is ONE iteration (STEP positions, everything requested above).  Longer slices
+    // ping-pong over two register sets so that two iterations of K rows are in flight (the second set is only ever
+    // loaded when the slice has a second iteration: nothing changes for short contexts).
+    constexpr uint32_t STEP = NGRP * PF;
+    const uint32_t niter = (n + STEP - 1) / STEP;  // block-uniform
+    auto load_rows = [&](const void *cache, f32x4 (&r)[PF], uint32_t it) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) r[u] = kv_load4<F16>(cache, (uint64_t)(t0 + min(it * STEP + grp + u * NGRP, n - 1)) * p.pos_stride + hbase);
+    };
+    auto scores = [&](const f32x4 (&r)[PF], uint32_t it) {
 #pragma unroll
         for (int u = 0; u < PF; u++) {
-            const uint32_t ii = i + u * NGRP;
+            const uint32_t ii = it * STEP + grp + u * NGRP;
 #pragma unroll
             for (int g = 0; g < G; g++) {
-                float d = qv[g][0] * kx[u][0];
-                d = fmaf(qv[g][1], kx[u][1], d);
-                d = fmaf(qv[g][2], kx[u][2], d);
-                d = fmaf(qv[g][3], kx[u][3], d);
+                float d = qv[g][0] * r[u][0];
+                d = fmaf(qv[g][1], r[u][1], d);
+                d = fmaf(qv[g][2], r[u][2], d);
+                d = fmaf(qv[g][3], r[u][3], d);
                 d = pos_sum<LPP>(d);
                 if (li == 0 && ii < n) sc[g * chunk_pad + ii] = d * scale;
             }
         }
-        if (i + NGRP * PF >= n) break;  // uniform per lane group; the sums above stay inside a group
-#pragma unroll
-        for (int u = 0; u < PF; u++)
-            kx[u] = kv_load4<F16>(p.kc, (uint64_t)(t0 + min(i + NGRP * PF + u * NGRP, n - 1)) * p.pos_stride + hbase);
+    };
+    f32x4 kxb[PF];
+    if (niter > 1) load_rows(p.kc, kxb, 1);
+    for (uint32_t it = 0; it < niter; it += 2) {
+        scores(kx, it);
+        if (it + 2 < niter) load_rows(p.kc, kx, it + 2);
+        if (it + 1 < niter) {
+            scores(kxb, it + 1);
+            if (it + 3 < niter) load_rows(p.kc, kxb, it + 3);
+        }
     }
     __syncthreads();
 
@@ -163,25 +178,31 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
     f32x4 acc[G];
 #pragma unroll
     for (int g = 0; g < G; g++) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (uint32_t i = grp;; i += NGRP * PF) {
+    auto weigh = [&](const f32x4 (&r)[PF], uint32_t it) {
 #pragma unroll
         for (int u = 0; u < PF; u++) {
-            const uint32_t ii = i + u * NGRP;
+            const uint32_t ii = it * STEP + grp + u * NGRP;
             if (ii < n) {
 #pragma unroll
                 for (int g = 0; g < G; g++) {
                     const float w = sc[g * chunk_pad + ii];
-                    acc[g][0] = fmaf(w, vx[u][0], acc[g][0]);
-                    acc[g][1] = fmaf(w, vx[u][1], acc[g][1]);
-                    acc[g][2] = fmaf(w, vx[u][2], acc[g][2]);
-                    acc[g][3] = fmaf(w, vx[u][3], acc[g][3]);
+                    acc[g][0] = fmaf(w, r[u][0], acc[g][0]);
+                    acc[g][1] = fmaf(w, r[u][1], acc[g][1]);
+                    acc[g][2] = fmaf(w, r[u][2], acc[g][2]);
+                    acc[g][3] = fmaf(w, r[u][3], acc[g][3]);
                 }
             }
         }
-        if (i + NGRP * PF >= n) break;
-#pragma unroll
-        for (int u = 0; u < PF; u++)
-            vx[u] = kv_load4<F16>(p.vc, (uint64_t)(t0 + min(i + NGRP * PF + u * NGRP, n - 1)) * p.pos_stride + hbase);
+    };
+    f32x4 vxb[PF];
+    if (niter > 1) load_rows(p.vc, vxb, 1);
+    for (uint32_t it = 0; it < niter; it += 2) {
+        weigh(vx, it);
+        if (it + 2 < niter) load_rows(p.vc, vx, it + 2);
+        if (it + 1 < niter) {
+            weigh(vxb, it + 1);
+            if (it + 3 < niter) load_rows(p.vc, vxb, it + 3);
+        }
     }
     // reduce over position groups through LDS: red[g][grp][D]
 #pragma unroll

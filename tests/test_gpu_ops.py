@@ -225,7 +225,8 @@ def test_silu_mul_add_embed_argmax(mgr):
 # ---- fused operators vs the unfused oracle chain, each at its own scale ----------------------
 @pytest.mark.parametrize("H,Hkv,D,S,C", [(32, 8, 64, 1, 64), (32, 8, 64, 15, 64), (32, 8, 64, 16, 64), (32, 8, 64, 17, 64),
                                          (32, 8, 64, 1024, 1024), (24, 8, 128, 5, 640), (24, 8, 128, 513, 640),
-                                         (24, 8, 128, 640, 640), (32, 8, 128, 300, 4096), (4, 2, 64, 33, 40), (8, 8, 128, 100, 128)])
+                                         (24, 8, 128, 640, 640), (32, 8, 128, 300, 4096), (4, 2, 64, 33, 40), (8, 8, 128, 100, 128),
+                                         (24, 8, 128, 4001, 4096), (32, 8, 64, 8000, 8192), (24, 8, 128, 1500, 2048)])  # multi-iteration slices
 @pytest.mark.parametrize("kv16", [False, True])
 def test_attn_decode_fused(mgr, H, Hkv, D, S, C, kv16):
     import ctypes as Cc
