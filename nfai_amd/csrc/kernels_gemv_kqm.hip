@@ -724,14 +724,15 @@ static hipError_t q4t_bpw(const KqmParams &p, int bpw, uint32_t grid, uint32_t b
     }
     if (bpw == 1) return q4t_launch<QT, MODE, 1>(p, ns, grid, block, lds, s);
     if (bpw == 2) return q4t_launch<QT, MODE, 2>(p, ns, grid, block, lds, s);
-    return q4t_launch<QT, MODE, 4>(p, ns, grid, block, lds, s);
+    if (bpw == 4) return q4t_launch<QT, MODE, 4>(p, ns, grid, block, lds, s);
+    return q4t_launch<QT, MODE, 8>(p, ns, grid, block, lds, s);
 }
 
 hipError_t launch_gemv_kqm(const GemvArgs &a, hipStream_t s)
 {
     if (a.w_type != NFAI_Q4_K_T16 && a.w_type != NFAI_Q6_K_T16 && a.w_type != NFAI_KQ_MIXED) return hipErrorInvalidValue;
     if (a.w_type == NFAI_KQ_MIXED && a.mode != GEMV_QKV_ROPE) return hipErrorInvalidValue;
-    if (a.K == 0 || a.K % 256 != 0 || a.K > 16384) return hipErrorInvalidValue;
+    if (a.K == 0 || a.K % 256 != 0 || a.K > 32768) return hipErrorInvalidValue;
     KqmParams p{};
     uint32_t total_tiles = 0;
     for (int i = 0; i < 3; i++) {
@@ -758,7 +759,7 @@ hipError_t launch_gemv_kqm(const GemvArgs &a, hipStream_t s)
     p.rope_cs = a.rope_cs; p.rope_dims = a.rope_dims; p.D = a.D ? a.D : 2; p.pos = a.pos_dev;
     p.kv_f16 = a.kv_type == NFAI_F16;
     p.seg6 = a.seg6_mask;
-    const int bpw = p.NB <= 16 ? 1 : (p.NB <= 32 ? 2 : 4);
+    const int bpw = p.NB <= 16 ? 1 : (p.NB <= 32 ? 2 : (p.NB <= 64 ? 4 : 8));  // K <= 32768 (Llama-70B: ffn length 28672)
     const uint32_t nw = (p.NB + bpw - 1) / bpw;
     static const int env_bpc = getenv("NFAI_KQM_BPC") ? atoi(getenv("NFAI_KQM_BPC")) : 1;  // sweep knobs
     static const int env_ub = getenv("NFAI_KQM_UB") ? atoi(getenv("NFAI_KQM_UB")) : 4;
@@ -767,7 +768,11 @@ hipError_t launch_gemv_kqm(const GemvArgs &a, hipStream_t s)
     p.UB = min((uint32_t)max(1, min(env_ub, 8)), min(upb, nw));
     const int R = a.mode == GEMV_GATEUP ? 2 : 1;
     const size_t nlay = a.w_type == NFAI_KQ_MIXED ? 2 : 1;  // fragment layouts staged
-    const size_t lds = nlay * ((size_t)nw * bpw * 1024 + (size_t)nw * bpw * 64) + (size_t)nw * bpw * 4 + (size_t)2 * p.UB * R * nw * 256 + 128;
+    auto lds_bytes = [&](uint32_t ub) {
+        return nlay * ((size_t)nw * bpw * 1024 + (size_t)nw * bpw * 64) + (size_t)nw * bpw * 4 + (size_t)2 * ub * R * nw * 256 + 128;
+    };
+    while (p.UB > 1 && lds_bytes(p.UB) > 160 * 1024) p.UB--;  // very long K: fewer units per reduction round
+    const size_t lds = lds_bytes(p.UB);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (a.w_type == NFAI_KQ_MIXED) return q4t_bpw<NFAI_KQ_MIXED, GEMV_QKV_ROPE>(p, bpw, grid, nw * 64, lds, s);
     if (a.w_type == NFAI_Q4_K_T16) {

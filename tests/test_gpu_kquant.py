@@ -44,7 +44,7 @@ def tol(Wd, x):
 
 
 @pytest.mark.parametrize("qt", [Q4_K, Q6_K])
-@pytest.mark.parametrize("N,K", [(2048, 2048), (1024, 3072), (512, 8192), (96, 256), (40, 768), (300, 14336), (7, 4096)])
+@pytest.mark.parametrize("N,K", [(2048, 2048), (1024, 3072), (512, 8192), (96, 256), (40, 768), (300, 14336), (7, 4096), (64, 28672), (304, 14336)])
 def test_gemv_kquant(mgr, qt, N, K):
     from nfai_amd.shaders import MatrixMultiplyShader
     r = rng(N + K + qt)
