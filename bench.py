@@ -273,7 +273,7 @@ def run_single(args):
         "prefill": prefill,
     }
     if not args.no_cpu_baseline:
-        n = args.cpu_tokens or 12
+        n = args.cpu_tokens or 128  # ~10-15 s of CPU work on the box's 16 host threads: the same token count as the GPU leg
         out["cpu_baseline"] = cpu_baseline(args, dims, weights, first_token, logits0, n)
     else:
         out["cpu_baseline"] = None
