@@ -152,6 +152,10 @@ int32_t nfai_hip_attn_decode(nfai_ctx_t ctx, nfai_buf_t q, nfai_buf_t kcache, nf
  * 5 / 6 / 7 = direct-to-LDS staging of 128x64 tiles with 2 / 3 / 4 stages. */
 int32_t nfai_hip_gemm_f16(nfai_ctx_t ctx, nfai_buf_t A_f16, nfai_buf_t W_f16, nfai_buf_t R, nfai_buf_t C, uint32_t M, uint32_t N,
                           uint32_t K, int32_t variant);
+/* The same batched product with W in Q4_K / Q6_K blocks (a buffer from nfai_hip_weight_upload with N %% 16 == 0 rows): the
+ * dequant-in-LDS GEMM — quantised bytes -> registers -> fp16 tile in LDS -> MFMA; the weights are never widened in HBM. */
+int32_t nfai_hip_gemm_kq(nfai_ctx_t ctx, nfai_buf_t A_f16, nfai_buf_t W, int32_t w_type, nfai_buf_t R, nfai_buf_t C, uint32_t M,
+                         uint32_t N, uint32_t K);
 int32_t nfai_hip_gemv_fused(nfai_ctx_t ctx, nfai_buf_t W, int32_t w_type, nfai_buf_t x, nfai_buf_t gamma,
                             float eps, nfai_buf_t res, nfai_buf_t y, uint32_t N, uint32_t K);
 /* RMSNorm -> Wgate, Wup GEMVs -> SiLU(gate) * up (TransformerBlock.cs:163-171 in one launch). */

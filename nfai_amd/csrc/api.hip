@@ -600,6 +600,33 @@ NFAI_API int32_t nfai_hip_gemm_f16(nfai_ctx_t h, nfai_buf_t A, nfai_buf_t W, nfa
     return NFAI_OK;
 }
 
+NFAI_API int32_t nfai_hip_gemm_kq(nfai_ctx_t h, nfai_buf_t A, nfai_buf_t W, int32_t type, nfai_buf_t R, nfai_buf_t C, uint32_t M, uint32_t N,
+                                  uint32_t K)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(ba, A);
+    BUF_OR_FAIL(bw, W);
+    BUF_OR_FAIL(bc, C);
+    Buf *br = R ? buf_of(R) : nullptr;
+    if (R && !br) return fail(NFAI_ERR_INVALID, "gemm_kq: invalid residual handle");
+    if (M == 0 || N % 64 || K % 256 || K == 0) return fail(NFAI_ERR_INVALID, "gemm_kq: needs M > 0, N %% 64 == 0, K %% 256 == 0 (M=%u N=%u K=%u)", M, N, K);
+    int lt;
+    { int rc = resolve_layout(__func__, bw, type, N, &lt); if (rc) return rc; }
+    if (lt != NFAI_Q4_K_T16 && lt != NFAI_Q6_K_T16)
+        return fail(NFAI_ERR_UNSUPPORTED, "gemm_kq: W must be a Q4_K / Q6_K buffer uploaded whole with a multiple of 16 rows");
+    NEED(ba, (uint64_t)M * K, 2);
+    NEED(bc, (uint64_t)M * N, 4);
+    if (br) NEED(br, (uint64_t)M * N, 4);
+    GemmArgs g;
+    g.A = ba->ptr; g.lda = K; g.B = bw->ptr; g.ldb = K; g.C = bc->ptr; g.ldc = N; g.b_type = lt;
+    g.R = br ? static_cast<const float *>(br->ptr) : nullptr;
+    g.M = M; g.N = N; g.K = K;
+    g.n_cu = (uint32_t)c->prop.multiProcessorCount;
+    hipError_t e = launch_gemm_kq(g, c->stream);
+    if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? NFAI_ERR_INVALID : NFAI_ERR_HIP, "gemm_kq: launch failed: %s", hipGetErrorString(e));
+    return NFAI_OK;
+}
+
 NFAI_API int32_t nfai_hip_gemv_fused(nfai_ctx_t h, nfai_buf_t W, int32_t type, nfai_buf_t x, nfai_buf_t gamma, float eps,
                                      nfai_buf_t res, nfai_buf_t y, uint32_t N, uint32_t K)
 {

@@ -125,10 +125,12 @@ struct GemmArgs {  // C[M][N] (+R) = alpha * A[M][K] * B[N][K]^T, fp16 operands,
     uint32_t batch = 1, b_div = 1;
     uint64_t a_bs = 0, b_bs = 0, c_bs = 0;
     float alpha = 1.0f;
+    int b_type = NFAI_F16;     // launch_gemm_kq: NFAI_Q4_K_T16 / NFAI_Q6_K_T16 (all weight segments of one type)
     int variant = 0;           // 0: chosen from the shape.  1: 128x64 tiles (4x1 waves)  2: 128x128 (2x2 waves)  3 / 4: direct-to-LDS 128x128, 2 / 3 stages  5 / 6 / 7: direct-to-LDS 128x64, 2 / 3 / 4 stages
     uint32_t causal = 0, causal_pos0 = 0;  // 1: C is a causal score matrix, 2: A is a causal probability matrix (skip masked tiles)
 };
 hipError_t launch_gemm_f16(const GemmArgs &a, hipStream_t s);
+hipError_t launch_gemm_kq(const GemmArgs &a, hipStream_t s);   // dequant-in-LDS GEMM on T16 K-quant weights
 hipError_t launch_f32_to_f16(const float *x, void *y_f16, uint64_t n, hipStream_t s);
 hipError_t launch_rmsnorm_rows(const float *x, const float *g, void *y_f16, uint32_t T, uint32_t E, float eps, hipStream_t s);
 hipError_t launch_rope_store_rows(const float *q, const float *k, const float *v, void *qh_f16, void *kc, void *vc, int kv_f16,

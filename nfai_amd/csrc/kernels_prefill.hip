@@ -295,6 +295,232 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void k_gemm_f16(const GemmParams p
     gemm_store<BM, BN, WM, WN, EPI, TM, TN>(acc, p, m0, n0, wm, wn, lane, batch);
 }
 
+// ---- dequant-in-LDS GEMM for K-quant weights (T16 layouts of kernels_gemv_kqm.hip) ---------------------------------------
+// C[M][N] (+R) = A[M][K] fp16 * W[N][K]^T with W in Q4_K / Q6_K blocks: the quantised bytes of a B tile (64 or 128 rows x 64 k:
+// 2.3 - 6.6 KB instead of 8 - 16 KB of fp16) go global -> VGPR, are expanded to fp16 by the thread that loaded them
+// (d * sc * q - dmin * m, resp. d * sc * (q - 32), rounded to fp16 exactly as a separate widening pass would) and written
+// into the same XOR-swizzled LDS tile the fp16 kernel uses; A staging, MFMA loop and epilogues are those of k_gemm_f16.
+// A 64-wide K tile is a quarter of a super-block: K tile kt -> super-block kt / 4, quarter c = kt % 4.
+//   Q4_K: quarter c = lane group G = c of the T16 layout: sub-blocks 2c (low nibbles) and 2c+1 (high nibbles).
+//         task (row, part 0..3) expands 16 weights: sub-block 2c + (part >> 1), bytes 16 (part & 1) .. +15 of the row's 32.
+//   Q6_K: quarter c = half n = c >> 1, ggml quarters 2 (c & 1) + {0, 1}; task (row, part): quarter 2 (c & 1) + (part >> 1),
+//         columns 16 (part & 1) .. +15 = lane group 2 n + (part & 1).
+template <int QT> struct KqTask;
+template <> struct KqTask<NFAI_Q4_K_T16> { u32x4 qs, hdr; };
+template <> struct KqTask<NFAI_Q6_K_T16> { u32x4 ql, qh, sc; uint32_t d; };
+
+template <int QT, int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256) void k_gemm_kq(const GemmParams p)
+{
+    constexpr int NT = 256, BK = 64, CH = 8, RING = 3;
+    constexpr int AN = BM * CH / NT;       // A chunks per thread per tile
+    constexpr int BT = BN * 4 / NT;        // B tasks (16 weights each) per thread per tile
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int TILE_BYTES = (BM + BN) * BK * 2;
+    static_assert(WM * WN == 4 && BT >= 1, "256 threads");
+    static_assert(EPI != EPI_SILU || BN / WN == 64, "SiLU epilogue pairs columns inside a 64-wide wave slice");
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    auto ldsA = [&](int buf) -> uint8_t * { return lds + buf * TILE_BYTES; };
+    auto ldsB = [&](int buf) -> uint8_t * { return lds + buf * TILE_BYTES + BM * BK * 2; };
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WN, wn = wave % WN;
+    const uint32_t tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
+    uint32_t mt_i, nt_i;
+    {
+        const uint32_t id = blockIdx.x;
+        if (tiles_n % 8 == 0) {
+            const uint32_t xcd = id & 7, slot = id >> 3;
+            nt_i = (slot / tiles_m) * 8 + xcd;
+            mt_i = slot % tiles_m;
+        } else {
+            nt_i = id / tiles_m;
+            mt_i = id % tiles_m;
+        }
+    }
+    const uint32_t m0 = mt_i * BM, n0 = nt_i * BN, batch = blockIdx.y;
+    const GLOBAL_AS uint8_t *Ab = (const GLOBAL_AS uint8_t *)p.A;
+    const uint32_t NB = p.K / 256;
+    // per task: weight tensor, row inside it, rows of that tensor (the header planes sit behind rows * NB blocks)
+    const GLOBAL_AS uint8_t *wbase[BT];
+    uint32_t wrow[BT], part[BT];
+    uint64_t wnblk[BT];
+#pragma unroll
+    for (int i = 0; i < BT; i++) {
+        const uint32_t c = tid + i * NT, row = c >> 2;
+        part[i] = c & 3;
+        if constexpr (EPI == EPI_SILU) {
+            const uint32_t sl = row >> 6, cc = row & 63;
+            wbase[i] = (const GLOBAL_AS uint8_t *)(cc < 32 ? p.B[0] : p.B[1]);
+            wrow[i] = n0 / 2 + sl * 32 + (cc & 31);
+            wnblk[i] = (uint64_t)p.seg_end[0] * NB;  // gate and up have N / 2 rows each
+        } else {
+            const uint32_t n = n0 + row;
+            const uint32_t seg = n < p.seg_end[0] ? 0u : (n < p.seg_end[1] ? 1u : 2u);
+            const uint32_t s0 = seg == 0 ? 0u : p.seg_end[seg - 1];
+            wbase[i] = (const GLOBAL_AS uint8_t *)p.B[seg];
+            wrow[i] = n - s0;
+            wnblk[i] = (uint64_t)(p.seg_end[seg] - s0) * NB;
+        }
+    }
+
+    u32x4 ra[RING][AN];
+    KqTask<QT> rb[RING][BT];
+    auto load_tile = [&](u32x4 (&a)[AN], KqTask<QT> (&b)[BT], uint32_t kt) {
+        const uint32_t k0 = kt * BK, blk = kt >> 2, c4 = kt & 3;
+#pragma unroll
+        for (int i = 0; i < AN; i++) {
+            const uint32_t c = tid + i * NT, row = c / CH, q = c % CH;
+            const uint32_t gr = min(m0 + row, p.M - 1);
+            a[i] = *reinterpret_cast<const GLOBAL_AS u32x4 *>(Ab + ((uint64_t)gr * p.lda + k0 + q * 8) * 2);
+        }
+#pragma unroll
+        for (int i = 0; i < BT; i++) {
+            const uint64_t tb = (uint64_t)(wrow[i] >> 4) * NB + blk;
+            const uint32_t r = wrow[i] & 15;
+            if constexpr (QT == NFAI_Q4_K_T16) {
+                b[i].qs = *reinterpret_cast<const GLOBAL_AS u32x4 *>(wbase[i] + tb * 2048 + (part[i] & 1) * 1024 + (c4 * 16 + r) * 16);
+                b[i].hdr = *reinterpret_cast<const GLOBAL_AS u32x4 *>(wbase[i] + wnblk[i] * 128 + tb * 256 + r * 16);
+            } else {
+                const uint32_t qd = 2 * (c4 & 1) + (part[i] >> 1), G = 2 * (c4 >> 1) + (part[i] & 1);
+                b[i].ql = *reinterpret_cast<const GLOBAL_AS u32x4 *>(wbase[i] + tb * 3072 + (qd & 1) * 1024 + (G * 16 + r) * 16);
+                b[i].qh = *reinterpret_cast<const GLOBAL_AS u32x4 *>(wbase[i] + tb * 3072 + 2048 + (G * 16 + r) * 16);
+                b[i].sc = *reinterpret_cast<const GLOBAL_AS u32x4 *>(wbase[i] + wnblk[i] * 192 + tb * 256 + r * 16);
+                b[i].d = *reinterpret_cast<const GLOBAL_AS uint16_t *>(wbase[i] + wnblk[i] * 208 + tb * 32 + r * 2);
+            }
+        }
+    };
+    auto store_tile = [&](const u32x4 (&a)[AN], const KqTask<QT> (&b)[BT], int buf, uint32_t kt) {
+        const uint32_t c4 = kt & 3;
+#pragma unroll
+        for (int i = 0; i < AN; i++) {
+            const uint32_t c = tid + i * NT, row = c / CH, q = c % CH;
+            *reinterpret_cast<u32x4 *>(ldsA(buf) + lds_off<CH>(row, q)) = a[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BT; i++) {
+            const uint32_t row = (tid + i * NT) >> 2, pt = part[i];
+            f16x8 o[2];
+            if constexpr (QT == NFAI_Q4_K_T16) {
+                const float d = h2f_lo(b[i].hdr[0]), dmin = h2f_hi(b[i].hdr[0]);
+                const uint32_t sb = 2 * c4 + (pt >> 1), sh = (sb & 3) * 8;
+                const uint32_t lo8 = (b[i].hdr[1] >> sh) & 0xFFu, mid = (b[i].hdr[2] >> sh) & 0xFFu, hi8 = (b[i].hdr[3] >> sh) & 0xFFu;
+                const bool low = sb < 4;
+                const uint32_t sc = low ? (lo8 & 63u) : ((hi8 & 0xFu) | ((lo8 >> 6) << 4));
+                const uint32_t mn = low ? (mid & 63u) : ((hi8 >> 4) | ((mid >> 6) << 4));
+                const float d1 = d * (float)sc, m1 = dmin * (float)mn;
+                const uint32_t nsh = (pt >> 1) * 4;  // high nibbles for the odd sub-block
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const uint32_t q = (b[i].qs[e >> 2] >> (8 * (e & 3) + nsh)) & 0xFu;
+                    o[e >> 3][e & 7] = (_Float16)(d1 * (float)q - m1);
+                }
+            } else {
+                const uint32_t qd = 2 * (c4 & 1) + (pt >> 1), si = 8 * (c4 >> 1) + (pt & 1) + 2 * qd;
+                const uint32_t sw = si < 8 ? (si < 4 ? b[i].sc[0] : b[i].sc[1]) : (si < 12 ? b[i].sc[2] : b[i].sc[3]);
+                const float dsc = h2f_lo(b[i].d) * (float)(int)(int8_t)((sw >> ((si & 3) * 8)) & 0xFFu);
+                const uint32_t nsh = (qd >> 1) * 4;
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const uint32_t lb = (b[i].ql[e >> 2] >> (8 * (e & 3) + nsh)) & 0xFu;
+                    const uint32_t hb = (b[i].qh[e >> 2] >> (8 * (e & 3) + 2 * qd)) & 3u;
+                    o[e >> 3][e & 7] = (_Float16)(dsc * (float)((int)(lb | (hb << 4)) - 32));
+                }
+            }
+            const uint32_t chunk0 = (pt >> 1) * 4 + (pt & 1) * 2;  // 16 consecutive k of the tile = two 16-byte chunks
+            *reinterpret_cast<f16x8 *>(ldsB(buf) + lds_off<CH>(row, chunk0)) = o[0];
+            *reinterpret_cast<f16x8 *>(ldsB(buf) + lds_off<CH>(row, chunk0 + 1)) = o[1];
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int cur) {
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ks++) {
+            const uint32_t chunk = ks * 4 + (lane >> 4);
+            f16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) af[i] = *reinterpret_cast<const f16x8 *>(ldsA(cur) + lds_off<CH>(wm * (BM / WM) + i * 16 + (lane & 15), chunk));
+#pragma unroll
+            for (int j = 0; j < TN; j++) bf[j] = *reinterpret_cast<const f16x8 *>(ldsB(cur) + lds_off<CH>(wn * (BN / WN) + j * 16 + (lane & 15), chunk));
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const uint32_t KT = p.K / BK;
+#pragma unroll
+    for (int r = 0; r < RING - 1; r++) load_tile(ra[r], rb[r], min((uint32_t)r, KT - 1));
+    store_tile(ra[0], rb[0], 0, 0);
+    __syncthreads();
+    for (uint32_t kt0 = 0; kt0 < KT; kt0 += RING) {  // same ring as k_gemm_f16: nothing conditional except the MFMAs past the end
+#pragma unroll
+        for (int r = 0; r < RING; r++) {
+            const uint32_t kt = kt0 + r;
+            load_tile(ra[(r + RING - 1) % RING], rb[(r + RING - 1) % RING], min(kt + RING - 1, KT - 1));
+            if (kt < KT) compute(kt & 1);
+            store_tile(ra[(r + 1) % RING], rb[(r + 1) % RING], (kt + 1) & 1, min(kt + 1, KT - 1));
+            __syncthreads();
+        }
+    }
+    gemm_store<BM, BN, WM, WN, EPI, TM, TN>(acc, p, m0, n0, wm, wn, lane, batch);
+}
+
+template <int QT, int EPI>
+static hipError_t gemm_kq_pick(const GemmParams &p, uint32_t n_cu, hipStream_t s)
+{
+    const uint64_t big_tiles = (uint64_t)((p.M + 127) / 128) * (p.N / 128);
+    if (p.N % 128 == 0 && big_tiles >= (uint64_t)n_cu * 3 / 2) {
+        constexpr int LDS = 2 * (128 + 128) * 64 * 2;
+        hipLaunchKernelGGL((k_gemm_kq<QT, 128, 128, 2, 2, EPI>), dim3((uint32_t)big_tiles, 1, 1), dim3(256), LDS, s, p);
+    } else {
+        constexpr int LDS = 2 * (128 + 64) * 64 * 2;
+        hipLaunchKernelGGL((k_gemm_kq<QT, 128, 64, 4, 1, EPI>), dim3(((p.M + 127) / 128) * (p.N / 64), 1, 1), dim3(256), LDS, s, p);
+    }
+    return hipGetLastError();
+}
+
+// W segments are T16 K-quant tensors of ONE type (a.b_type); fp16 A, fp32 C (+R) or the SiLU*up fp16 epilogue.
+hipError_t launch_gemm_kq(const GemmArgs &a, hipStream_t s)
+{
+    if (a.M == 0 || a.N == 0) return hipSuccess;
+    if (a.b_type != NFAI_Q4_K_T16 && a.b_type != NFAI_Q6_K_T16) return hipErrorInvalidValue;
+    if (a.N % 64 != 0 || a.K % 256 != 0 || a.K == 0 || a.lda % 8 != 0 || (a.batch > 1)) return hipErrorInvalidValue;
+    GemmParams p{};
+    p.A = static_cast<const _Float16 *>(a.A);
+    p.B[0] = static_cast<const _Float16 *>(a.B);
+    p.B[1] = static_cast<const _Float16 *>(a.B1 ? a.B1 : a.B);
+    p.B[2] = static_cast<const _Float16 *>(a.B2 ? a.B2 : a.B);
+    p.seg_end[0] = a.B1 ? a.n0 : a.N;
+    p.seg_end[1] = a.B2 ? a.n0 + a.n1 : a.N;
+    p.seg_end[2] = a.N;
+    p.C = a.C; p.R = a.R;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.lda = a.lda; p.ldb = a.K; p.ldc = a.ldc;
+    p.b_div = 1; p.alpha = a.alpha; p.ksplit = 1;
+    const uint32_t n_cu = a.n_cu ? a.n_cu : 256;
+    if (a.epi == EPI_SILU) {
+        if (!a.B1 || a.n0 * 2 != a.N || a.R || a.n0 % 64) return hipErrorInvalidValue;
+        return a.b_type == NFAI_Q4_K_T16 ? gemm_kq_pick<NFAI_Q4_K_T16, EPI_SILU>(p, n_cu, s) : gemm_kq_pick<NFAI_Q6_K_T16, EPI_SILU>(p, n_cu, s);
+    }
+    if (a.epi != EPI_F32) return hipErrorInvalidValue;
+    // a tile must not straddle a segment boundary (rows of a tile address one tensor's planes)
+    const uint32_t gran = (p.N % 128 == 0 && (p.seg_end[0] | p.seg_end[1]) % 128 == 0) ? 128u : 64u;
+    if ((p.seg_end[0] | p.seg_end[1]) % 64) return hipErrorInvalidValue;
+    if (gran == 64) {
+        constexpr int LDS = 2 * (128 + 64) * 64 * 2;
+        const dim3 grid(((p.M + 127) / 128) * (p.N / 64), 1, 1);
+        if (a.b_type == NFAI_Q4_K_T16) hipLaunchKernelGGL((k_gemm_kq<NFAI_Q4_K_T16, 128, 64, 4, 1, EPI_F32>), grid, dim3(256), LDS, s, p);
+        else hipLaunchKernelGGL((k_gemm_kq<NFAI_Q6_K_T16, 128, 64, 4, 1, EPI_F32>), grid, dim3(256), LDS, s, p);
+        return hipGetLastError();
+    }
+    return a.b_type == NFAI_Q4_K_T16 ? gemm_kq_pick<NFAI_Q4_K_T16, EPI_F32>(p, n_cu, s) : gemm_kq_pick<NFAI_Q6_K_T16, EPI_F32>(p, n_cu, s);
+}
+
 // ---- direct-to-LDS variants (128 x 128 x 64 tiles with 2 x 2 waves of 64 x 64; 128 x 64 x 64 with 4 x 1 waves) --------------
 // Operands go global -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write pass); NST LDS stages, tile kt + NST - 1
 // is requested while tile kt is multiplied.  One raw s_barrier per K tile:

@@ -175,3 +175,32 @@ def test_prefill_mfma_kquant(mgr, n, chunk):
         assert np.abs(lg - wl).max() <= tol5
         tok = orc.argmax(wl)
     m.Dispose()
+
+
+@pytest.mark.parametrize("qt", [Q4_K, Q6_K])
+@pytest.mark.parametrize("M,N,K,res", [(256, 512, 1024, True), (100, 64, 256, False), (512, 3072, 768, False)])
+def test_gemm_kq_dequant_in_lds(mgr, qt, M, N, K, res):
+    """The dequant-in-LDS GEMM (k_gemm_kq: quantised bytes -> registers -> fp16 tile in LDS -> MFMA) against fp64 NumPy on the
+    oracle's dequantised weights ROUNDED TO fp16 (the kernel forms d*sc*q - dmin*m in fp32 and rounds to fp16 on the way into
+    LDS, like the separate widening pass): with identical operands the error is fp32 summation-order noise.  Covers both tile
+    configurations (N = 3072 at M = 512 takes 128x128), ragged M and the residual epilogue."""
+    from nfai_amd._lib import call
+    from nfai_amd.hip import ShaderProperty
+    r = rng(7 * M + N + K + qt)
+    W = (0.02 * r.standard_normal((N, K))).astype(np.float32)
+    raw, Wd = quantize(W, qt)
+    A = r.standard_normal((M, K)).astype(np.float16)
+    R = r.standard_normal((M, N)).astype(np.float32) if res else None
+    wbuf = mgr.UploadWeight(qt, raw, N, K)
+    pa, pc = ShaderProperty(mgr, M * K, np.float16), ShaderProperty(mgr, M * N, np.float32)
+    pa.SetValue(A.ravel())
+    pr = None
+    if res:
+        pr = ShaderProperty(mgr, M * N, np.float32)
+        pr.SetValue(R.ravel())
+    call("nfai_hip_gemm_kq", mgr.handle, pa.handle, wbuf.handle, qt, pr.handle if res else 0, pc.handle, M, N, K)
+    got = pc.GetValue().reshape(M, N)
+    W16 = Wd.astype(np.float16).astype(np.float64)
+    want = A.astype(np.float64) @ W16.T + (R.astype(np.float64) if res else 0.0)
+    scale = float(np.abs(A.astype(np.float64)).mean() * np.abs(W16).mean() * K)
+    assert np.abs(got - want).max() <= 2e-6 * np.sqrt(K) * scale + 1e-5, np.abs(got - want).max()
