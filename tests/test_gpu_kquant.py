@@ -204,3 +204,27 @@ def test_gemm_kq_dequant_in_lds(mgr, qt, M, N, K, res):
     want = A.astype(np.float64) @ W16.T + (R.astype(np.float64) if res else 0.0)
     scale = float(np.abs(A.astype(np.float64)).mean() * np.abs(W16).mean() * K)
     assert np.abs(got - want).max() <= 2e-6 * np.sqrt(K) * scale + 1e-5, np.abs(got - want).max()
+
+
+@pytest.mark.parametrize("qt", [Q4_K, Q6_K])
+@pytest.mark.parametrize("xscale", [0.0, 1e-30, 1e-6, 3e4], ids=["zero", "tiny", "small", "large"])
+def test_gemv_kquant_activation_range(mgr, qt, xscale):
+    """The int8-MFMA GEMV turns every 256-element super-block of x into fixed point with its own power-of-two scale: the result
+    must track the fp32 oracle over the whole dynamic range (all-zero input, magnitudes far below and above 1, and one
+    super-block 10^6 times larger than its neighbours)."""
+    from nfai_amd.shaders import MatrixMultiplyShader
+    N, K = 256, 2048
+    r = rng(1000 + qt)
+    W = (0.02 * r.standard_normal((N, K))).astype(np.float32)
+    raw, Wd = quantize(W, qt)
+    x = (xscale * r.standard_normal(K)).astype(np.float32)
+    if xscale == 1e-6:
+        x[256:512] *= 1e6  # one loud super-block beside quiet ones
+    op = MatrixMultiplyShader(mgr, 1, K, N, None)
+    op.GetWeightProperty().set(raw, qt, N, K)
+    op.GetInputProperty().SetValue(x)
+    op.Compute()
+    got = op.GetOutputs()
+    ref = orc.gemv(Wd, x)
+    assert np.isfinite(got).all()
+    assert (np.abs(got - ref) <= tol(Wd, x) + 1e-30).all(), (np.abs(got - ref).max(), tol(Wd, x).min())
