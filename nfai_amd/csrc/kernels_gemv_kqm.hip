@@ -759,7 +759,9 @@ hipError_t launch_gemv_kqm(const GemvArgs &a, hipStream_t s)
     p.rope_cs = a.rope_cs; p.rope_dims = a.rope_dims; p.D = a.D ? a.D : 2; p.pos = a.pos_dev;
     p.kv_f16 = a.kv_type == NFAI_F16;
     p.seg6 = a.seg6_mask;
-    const int bpw = p.NB <= 16 ? 1 : (p.NB <= 32 ? 2 : (p.NB <= 64 ? 4 : 8));  // K <= 32768 (Llama-70B: ffn length 28672)
+    static const int env_bpw = getenv("NFAI_KQM_BPW") ? atoi(getenv("NFAI_KQM_BPW")) : 0;  // sweep knob: super-blocks per wave
+    int bpw = p.NB <= 16 ? 1 : (p.NB <= 32 ? 2 : (p.NB <= 64 ? 4 : 8));  // K <= 32768 (Llama-70B: ffn length 28672)
+    if ((env_bpw == 2 || env_bpw == 4) && env_bpw > bpw && p.NB % env_bpw == 0) bpw = env_bpw;
     const uint32_t nw = (p.NB + bpw - 1) / bpw;
     static const int env_bpc = getenv("NFAI_KQM_BPC") ? atoi(getenv("NFAI_KQM_BPC")) : 1;  // sweep knobs
     static const int env_ub = getenv("NFAI_KQM_UB") ? atoi(getenv("NFAI_KQM_UB")) : 4;
