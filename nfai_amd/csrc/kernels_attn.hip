@@ -88,7 +88,11 @@ __device__ __forceinline__ void st_agent(float *p, float v) { __hip_atomic_store
 __device__ __forceinline__ float ld_agent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // LPP = lanes per position = D/4 (16 for D=64, 32 for D=128); G = query heads per kv head.
-template <int LPP, int G, bool F16>
+// ONLINE: one pass over the slice — every lane group keeps a running (max, sum of exp, weighted V) for the positions it
+// visits (online softmax), K and V rows of an iteration are requested together, and the groups are combined once at the
+// end; the two-pass form (scores -> LDS, softmax by one wave per head, then V) needs two more barriers and walks K and V
+// one after the other.
+template <int LPP, int G, bool F16, bool ONLINE>
 __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
 {
     constexpr int D = LPP * 4;
@@ -123,92 +127,176 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
             (const __attribute__((address_space(1))) float *)p.q + (uint64_t)(kvh * G + g) * D + li * 4);
     const float scale = 1.0f / sqrtf((float)D);  // …ScoreCalculationShader.cs:93
 
-    // ---- phase 1: scores of the slice -> LDS ------------------------------------------------
-    // A slice of the benchmark's context is ONE iteration (STEP positions, everything requested above).  Longer slices
-    // ping-pong over two register sets so that two iterations of K rows are in flight (the second set is only ever
-    // loaded when the slice has a second iteration: nothing changes for short contexts).
-    constexpr uint32_t STEP = NGRP * PF;
-    const uint32_t niter = (n + STEP - 1) / STEP;  // block-uniform
-    auto load_rows = [&](const void *cache, f32x4 (&r)[PF], uint32_t it) {
-#pragma unroll
-        for (int u = 0; u < PF; u++) r[u] = kv_load4<F16>(cache, (uint64_t)(t0 + min(it * STEP + grp + u * NGRP, n - 1)) * p.pos_stride + hbase);
-    };
-    auto scores = [&](const f32x4 (&r)[PF], uint32_t it) {
-#pragma unroll
-        for (int u = 0; u < PF; u++) {
-            const uint32_t ii = it * STEP + grp + u * NGRP;
-#pragma unroll
-            for (int g = 0; g < G; g++) {
-                float d = qv[g][0] * r[u][0];
-                d = fmaf(qv[g][1], r[u][1], d);
-                d = fmaf(qv[g][2], r[u][2], d);
-                d = fmaf(qv[g][3], r[u][3], d);
-                d = pos_sum<LPP>(d);
-                if (li == 0 && ii < n) sc[g * chunk_pad + ii] = d * scale;
-            }
-        }
-    };
-    // long slices: NSET register sets of rows in flight; the loads are unconditional (clamped to the last iteration) so
-    // that hipcc's vmcnt bookkeeping stays exact; only the arithmetic is skipped past the end
-    auto pipe = [&](auto nset_tag, const void *cache, f32x4 (&first)[PF], auto &&use) {
-        constexpr int NSET = decltype(nset_tag)::value;
-        f32x4 extra[NSET - 1][PF];
-#pragma unroll
-        for (int j = 1; j < NSET; j++) load_rows(cache, extra[j - 1], min((uint32_t)j, niter - 1));
-        for (uint32_t it = 0; it < niter; it += NSET) {
-            use(first, it);
-            load_rows(cache, first, min(it + NSET, niter - 1));
-#pragma unroll
-            for (int j = 1; j < NSET; j++) {
-                if (it + j < niter) use(extra[j - 1], it + j);
-                load_rows(cache, extra[j - 1], min(it + j + NSET, niter - 1));
-            }
-        }
-    };
-    // two sets (measured at 8192 positions: four sets change nothing — 64 KB in flight per CU is not the limit there, the
-    // sequential K phase / V phase / hand-off structure is)
-    if (niter == 1) scores(kx, 0);
-    else pipe(std::integral_constant<int, 2>{}, p.kc, kx, scores);
-    __syncthreads();
-
-    // ---- phase 2: slice max, exp, sum (AttentionSoftmaxShader.cs:148-169 on the slice) -----------
-    for (uint32_t g = tid >> 6; g < (uint32_t)G; g += ATTN_BLOCK / 64) {  // wave per query head
-        float m = -1.0e38f;
-        for (uint32_t t = lane; t < n; t += 64) m = fmaxf(m, sc[g * chunk_pad + t]);
-        m = wave_max(m);
-        float sum = 0.f;
-        for (uint32_t t = lane; t < n; t += 64) {
-            const float e = expf(sc[g * chunk_pad + t] - m);
-            sc[g * chunk_pad + t] = e;
-            sum += e;
-        }
-        sum = wave_sum(sum);
-        if (lane == 0) { stat[g * 2] = m; stat[g * 2 + 1] = sum; }
-    }
-    __syncthreads();
-
-    // ---- phase 3: weighted V sum over the slice ---------------------------------------------
     f32x4 acc[G];
 #pragma unroll
     for (int g = 0; g < G; g++) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto weigh = [&](const f32x4 (&r)[PF], uint32_t it) {
+    if constexpr (ONLINE) {
+        constexpr uint32_t STEP = NGRP * PF;
+        const uint32_t niter = (n + STEP - 1) / STEP;  // block-uniform
+        float m[G], l[G];
 #pragma unroll
-        for (int u = 0; u < PF; u++) {
-            const uint32_t ii = it * STEP + grp + u * NGRP;
-            if (ii < n) {
+        for (int g = 0; g < G; g++) { m[g] = -1.0e38f; l[g] = 0.f; }
+        auto load_kv = [&](f32x4 (&kr)[PF], f32x4 (&vr)[PF], uint32_t it) {
+#pragma unroll
+            for (int u = 0; u < PF; u++) kr[u] = kv_load4<F16>(p.kc, (uint64_t)(t0 + min(it * STEP + grp + u * NGRP, n - 1)) * p.pos_stride + hbase);
+#pragma unroll
+            for (int u = 0; u < PF; u++) vr[u] = kv_load4<F16>(p.vc, (uint64_t)(t0 + min(it * STEP + grp + u * NGRP, n - 1)) * p.pos_stride + hbase);
+        };
+        auto step = [&](const f32x4 (&kr)[PF], const f32x4 (&vr)[PF], uint32_t it) {
+            float sv[PF][G];
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const bool live = it * STEP + grp + u * NGRP < n;
 #pragma unroll
                 for (int g = 0; g < G; g++) {
-                    const float w = sc[g * chunk_pad + ii];
-                    acc[g][0] = fmaf(w, r[u][0], acc[g][0]);
-                    acc[g][1] = fmaf(w, r[u][1], acc[g][1]);
-                    acc[g][2] = fmaf(w, r[u][2], acc[g][2]);
-                    acc[g][3] = fmaf(w, r[u][3], acc[g][3]);
+                    float d = qv[g][0] * kr[u][0];
+                    d = fmaf(qv[g][1], kr[u][1], d);
+                    d = fmaf(qv[g][2], kr[u][2], d);
+                    d = fmaf(qv[g][3], kr[u][3], d);
+                    d = pos_sum<LPP>(d);
+                    sv[u][g] = live ? d * scale : -1.0e38f;
                 }
             }
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                float mn = m[g];
+#pragma unroll
+                for (int u = 0; u < PF; u++) mn = fmaxf(mn, sv[u][g]);
+                const float c = __expf(m[g] - mn);  // 1 while nothing has been seen (both -1e38); v_exp_f32 path: 15 exponentials per iteration
+                l[g] *= c;
+                acc[g] *= c;
+#pragma unroll
+                for (int u = 0; u < PF; u++) {
+                    const bool live = it * STEP + grp + u * NGRP < n;
+                    const float e = live ? __expf(sv[u][g] - mn) : 0.f;
+                    l[g] += e;
+                    acc[g][0] = fmaf(e, vr[u][0], acc[g][0]);
+                    acc[g][1] = fmaf(e, vr[u][1], acc[g][1]);
+                    acc[g][2] = fmaf(e, vr[u][2], acc[g][2]);
+                    acc[g][3] = fmaf(e, vr[u][3], acc[g][3]);
+                }
+                m[g] = mn;
+            }
+        };
+        if (niter == 1) {
+            step(kx, vx, 0);
+        } else {
+            f32x4 kb[PF], vb[PF];
+            load_kv(kb, vb, 1);
+            for (uint32_t it = 0; it < niter; it += 2) {  // unconditional, clamped loads: exact vmcnt bookkeeping
+                step(kx, vx, it);
+                load_kv(kx, vx, min(it + 2, niter - 1));
+                if (it + 1 < niter) step(kb, vb, it + 1);
+                load_kv(kb, vb, min(it + 3, niter - 1));
+            }
         }
-    };
-    if (niter == 1) weigh(vx, 0);
-    else pipe(std::integral_constant<int, 2>{}, p.vc, vx, weigh);
+        // combine the lane groups: block max per head, rescale, block sum of exp
+        float *gstat = red + G * NGRP * D;  // [G][NGRP][2]
+        if (li == 0) {
+#pragma unroll
+            for (int g = 0; g < G; g++) { gstat[(g * NGRP + grp) * 2] = m[g]; gstat[(g * NGRP + grp) * 2 + 1] = l[g]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            float M = -1.0e38f;
+#pragma unroll
+            for (int r = 0; r < NGRP; r++) M = fmaxf(M, gstat[(g * NGRP + r) * 2]);
+            const float w = expf(m[g] - M);
+            acc[g] *= w;
+            if (tid == (uint32_t)g) {
+                float L = 0.f;
+#pragma unroll
+                for (int r = 0; r < NGRP; r++) L += gstat[(g * NGRP + r) * 2 + 1] * expf(gstat[(g * NGRP + r) * 2] - M);
+                stat[g * 2] = M;
+                stat[g * 2 + 1] = L;
+            }
+        }
+    } else {
+        // ---- phase 1: scores of the slice -> LDS ------------------------------------------------
+        // A slice of the benchmark's context is ONE iteration (STEP positions, everything requested above).  Longer slices
+        // ping-pong over two register sets so that two iterations of K rows are in flight (the second set is only ever
+        // loaded when the slice has a second iteration: nothing changes for short contexts).
+        constexpr uint32_t STEP = NGRP * PF;
+        const uint32_t niter = (n + STEP - 1) / STEP;  // block-uniform
+        auto load_rows = [&](const void *cache, f32x4 (&r)[PF], uint32_t it) {
+    #pragma unroll
+            for (int u = 0; u < PF; u++) r[u] = kv_load4<F16>(cache, (uint64_t)(t0 + min(it * STEP + grp + u * NGRP, n - 1)) * p.pos_stride + hbase);
+        };
+        auto scores = [&](const f32x4 (&r)[PF], uint32_t it) {
+    #pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const uint32_t ii = it * STEP + grp + u * NGRP;
+    #pragma unroll
+                for (int g = 0; g < G; g++) {
+                    float d = qv[g][0] * r[u][0];
+                    d = fmaf(qv[g][1], r[u][1], d);
+                    d = fmaf(qv[g][2], r[u][2], d);
+                    d = fmaf(qv[g][3], r[u][3], d);
+                    d = pos_sum<LPP>(d);
+                    if (li == 0 && ii < n) sc[g * chunk_pad + ii] = d * scale;
+                }
+            }
+        };
+        // long slices: NSET register sets of rows in flight; the loads are unconditional (clamped to the last iteration) so
+        // that hipcc's vmcnt bookkeeping stays exact; only the arithmetic is skipped past the end
+        auto pipe = [&](auto nset_tag, const void *cache, f32x4 (&first)[PF], auto &&use) {
+            constexpr int NSET = decltype(nset_tag)::value;
+            f32x4 extra[NSET - 1][PF];
+    #pragma unroll
+            for (int j = 1; j < NSET; j++) load_rows(cache, extra[j - 1], min((uint32_t)j, niter - 1));
+            for (uint32_t it = 0; it < niter; it += NSET) {
+                use(first, it);
+                load_rows(cache, first, min(it + NSET, niter - 1));
+    #pragma unroll
+                for (int j = 1; j < NSET; j++) {
+                    if (it + j < niter) use(extra[j - 1], it + j);
+                    load_rows(cache, extra[j - 1], min(it + j + NSET, niter - 1));
+                }
+            }
+        };
+        // two sets (measured at 8192 positions: four sets change nothing — 64 KB in flight per CU is not the limit there, the
+        // sequential K phase / V phase / hand-off structure is)
+        if (niter == 1) scores(kx, 0);
+        else pipe(std::integral_constant<int, 2>{}, p.kc, kx, scores);
+        __syncthreads();
+
+        // ---- phase 2: slice max, exp, sum (AttentionSoftmaxShader.cs:148-169 on the slice) -----------
+        for (uint32_t g = tid >> 6; g < (uint32_t)G; g += ATTN_BLOCK / 64) {  // wave per query head
+            float m = -1.0e38f;
+            for (uint32_t t = lane; t < n; t += 64) m = fmaxf(m, sc[g * chunk_pad + t]);
+            m = wave_max(m);
+            float sum = 0.f;
+            for (uint32_t t = lane; t < n; t += 64) {
+                const float e = expf(sc[g * chunk_pad + t] - m);
+                sc[g * chunk_pad + t] = e;
+                sum += e;
+            }
+            sum = wave_sum(sum);
+            if (lane == 0) { stat[g * 2] = m; stat[g * 2 + 1] = sum; }
+        }
+        __syncthreads();
+
+        // ---- phase 3: weighted V sum over the slice ---------------------------------------------
+        auto weigh = [&](const f32x4 (&r)[PF], uint32_t it) {
+    #pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const uint32_t ii = it * STEP + grp + u * NGRP;
+                if (ii < n) {
+    #pragma unroll
+                    for (int g = 0; g < G; g++) {
+                        const float w = sc[g * chunk_pad + ii];
+                        acc[g][0] = fmaf(w, r[u][0], acc[g][0]);
+                        acc[g][1] = fmaf(w, r[u][1], acc[g][1]);
+                        acc[g][2] = fmaf(w, r[u][2], acc[g][2]);
+                        acc[g][3] = fmaf(w, r[u][3], acc[g][3]);
+                    }
+                }
+            }
+        };
+        if (niter == 1) weigh(vx, 0);
+        else pipe(std::integral_constant<int, 2>{}, p.vc, vx, weigh);
+    }
     // reduce over position groups through LDS: red[g][grp][D]
 #pragma unroll
     for (int g = 0; g < G; g++) *reinterpret_cast<f32x4 *>(red + ((uint32_t)g * NGRP + grp) * D + li * 4) = acc[g];
@@ -288,15 +376,15 @@ size_t attn_partials_bytes(uint32_t H, uint32_t Hkv, uint32_t D)
     return (size_t)H * ATTN_NSPLIT_MAX * (D + 2) * sizeof(float) + 256;
 }
 
-template <int LPP, bool F16>
+template <int LPP, bool F16, bool ONLINE>
 static hipError_t launch_g(const AttnParams &p, uint32_t G, dim3 grid, size_t lds, hipStream_t s)
 {
     switch (G) {
-        case 1: hipLaunchKernelGGL((k_attn_decode<LPP, 1, F16>), grid, dim3(ATTN_BLOCK), lds, s, p); break;
-        case 2: hipLaunchKernelGGL((k_attn_decode<LPP, 2, F16>), grid, dim3(ATTN_BLOCK), lds, s, p); break;
-        case 3: hipLaunchKernelGGL((k_attn_decode<LPP, 3, F16>), grid, dim3(ATTN_BLOCK), lds, s, p); break;
-        case 4: hipLaunchKernelGGL((k_attn_decode<LPP, 4, F16>), grid, dim3(ATTN_BLOCK), lds, s, p); break;
-        case 8: hipLaunchKernelGGL((k_attn_decode<LPP, 8, F16>), grid, dim3(ATTN_BLOCK), lds, s, p); break;
+        case 1: hipLaunchKernelGGL((k_attn_decode<LPP, 1, F16, ONLINE>), grid, dim3(ATTN_BLOCK), lds, s, p); break;
+        case 2: hipLaunchKernelGGL((k_attn_decode<LPP, 2, F16, ONLINE>), grid, dim3(ATTN_BLOCK), lds, s, p); break;
+        case 3: hipLaunchKernelGGL((k_attn_decode<LPP, 3, F16, ONLINE>), grid, dim3(ATTN_BLOCK), lds, s, p); break;
+        case 4: hipLaunchKernelGGL((k_attn_decode<LPP, 4, F16, ONLINE>), grid, dim3(ATTN_BLOCK), lds, s, p); break;
+        case 8: hipLaunchKernelGGL((k_attn_decode<LPP, 8, F16, ONLINE>), grid, dim3(ATTN_BLOCK), lds, s, p); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -329,12 +417,21 @@ hipError_t launch_attn_decode(const AttnArgs &a, hipStream_t s)
     max_chunk = (max_chunk + 3) & ~3u;
     if (max_chunk < 2 * ATTN_NSPLIT_MAX) max_chunk = 2 * ATTN_NSPLIT_MAX;
     const uint32_t lpp = a.D / 4, ngrp = ATTN_BLOCK / lpp;
-    const size_t lds = (64 + (size_t)G * max_chunk + (size_t)G * ngrp * a.D + 64) * sizeof(float);
+    const size_t lds = (64 + (size_t)G * max_chunk + (size_t)G * ngrp * a.D + 64 + (size_t)G * ngrp * 2) * sizeof(float);  // + group stats of the one-pass form
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     const dim3 grid(a.Hkv, p.max_split);
     const bool f16 = a.kv_type == NFAI_F16;
-    if (a.D == 64) return f16 ? launch_g<16, true>(p, G, grid, lds, s) : launch_g<16, false>(p, G, grid, lds, s);
-    return f16 ? launch_g<32, true>(p, G, grid, lds, s) : launch_g<32, false>(p, G, grid, lds, s);
+    // One-pass (online softmax, v_exp_f32) or two-pass form.  The position is device-side, so the choice is made from the KV
+    // capacity the model was created with: above 2048 positions the one-pass form (8192 positions: 520 vs 493 tokens/s at
+    // 3B), otherwise the two-pass form, which mirrors the reference's three dispatches literally (max, exp(clamp), sum with
+    // libm expf) and is as fast at a few hundred positions (611 vs 610).  NFAI_ATTN_ONLINE=0/1 overrides.
+    static const int env_online = getenv("NFAI_ATTN_ONLINE") ? atoi(getenv("NFAI_ATTN_ONLINE")) : -1;
+    if (env_online == 1 || (env_online < 0 && a.C > 2048)) {
+        if (a.D == 64) return f16 ? launch_g<16, true, true>(p, G, grid, lds, s) : launch_g<16, false, true>(p, G, grid, lds, s);
+        return f16 ? launch_g<32, true, true>(p, G, grid, lds, s) : launch_g<32, false, true>(p, G, grid, lds, s);
+    }
+    if (a.D == 64) return f16 ? launch_g<16, true, false>(p, G, grid, lds, s) : launch_g<16, false, false>(p, G, grid, lds, s);
+    return f16 ? launch_g<32, true, false>(p, G, grid, lds, s) : launch_g<32, false, false>(p, G, grid, lds, s);
 }
 
 }  // namespace nfai
