@@ -136,6 +136,22 @@ def host_weights(weights):
     return host
 
 
+def probe_reference_vulkan_path():
+    """the reference itself (C#/.NET 9 + Vulkan on lavapipe) would be the preferred CPU baseline.  It needs a
+    .NET SDK, glslangValidator, a Vulkan loader + lavapipe ICD + validation layer (VulkanHelper.cs:14-17) and a real GGUF; this
+    probes for them on the box it runs on and says what is missing (nothing is installed or fetched)."""
+    import glob
+    import shutil
+    missing = [t for t in ("dotnet", "glslangValidator", "vulkaninfo") if shutil.which(t) is None]
+    if not any(glob.glob(p) for p in ("/usr/lib/x86_64-linux-gnu/libvulkan.so*", "/usr/lib64/libvulkan.so*", "/usr/local/lib/libvulkan.so*")):
+        missing.append("libvulkan")
+    if not any(glob.glob(p) for p in ("/usr/share/vulkan/icd.d/lvp_icd*.json", "/etc/vulkan/icd.d/lvp_icd*.json")):
+        missing.append("lavapipe ICD")
+    if not glob.glob(os.path.join(ROOT, "**", "*.gguf"), recursive=True):
+        missing.append("Llama GGUF file")
+    return ("available" if not missing else "reference Vulkan path unavailable on this box: missing " + ", ".join(missing))
+
+
 def cpu_baseline(args, dims, weights, first_token, gpu_logits0, n_tokens):
     """The oracle (a port of the reference path: fp32 math, reference summation order, OpenMP over
     output rows) timed on this box's host cores on a bounded sample of the SAME workload: the
@@ -158,7 +174,8 @@ def cpu_baseline(args, dims, weights, first_token, gpu_logits0, n_tokens):
     return {"value": n_tokens / dt, "unit": "tokens/s", "cores": orc.num_threads(), "kind": "port",
             "sample": f"first {n_tokens} greedy tokens of the same model from position 0 (oracle/nfai_oracle.c, fp32 math, "
                       f"{orc.num_threads()} OpenMP threads)",
-            "seconds": dt, "max_abs_logit_diff_vs_gpu_token0": err}
+            "seconds": dt, "max_abs_logit_diff_vs_gpu_token0": err,
+            "reference_vulkan_path": probe_reference_vulkan_path()}
 
 
 def run_single(args):
@@ -187,7 +204,17 @@ def run_single(args):
     prompt = synth.make_tokens(dims, args.context, seed=99)
     prompt[0] = first_token
     if not args.no_mfma_prefill:
-        m.Prefill(prompt, want_logits=False)          # warm (first-touch of the workspace)
+        # parity side-check of the MFMA prefill at the benchmark's own size: the same prompt through the decode path token by
+        # token (the reference's way, LlamaModel.cs:103-126) must give the same argmax and logits within the fp16 tolerance
+        m.SetToken(int(prompt[0]))
+        for t in prompt[:-1]:
+            m.Step(int(t), want_logits=False)
+        lg_dec, am_dec = m.Step(int(prompt[-1]))
+        m.Reset()
+        lg_pf = m.Prefill(prompt)                     # also warms the workspace (first touch)
+        pf_err = float(np.abs(lg_pf - lg_dec).max())
+        pf_tol = 5e-2 * max(1.0, float(np.abs(lg_dec).max()))
+        assert int(np.argmax(lg_pf)) == am_dec and pf_err <= pf_tol, f"MFMA prefill disagrees with the decode path: {pf_err} > {pf_tol}"
         m.Reset()
         mgr.Synchronize()
         mgr.TimerBegin()
@@ -199,6 +226,8 @@ def run_single(args):
         flops = dims.L * (per_layer + attn) + 2 * dims.V * dims.E
         prefill = {"tokens": T, "ms": pf_ms, "tokens_per_s": T / (pf_ms * 1e-3), "tflops": flops / (pf_ms * 1e-3) / 1e12,
                    "peak_tflops": 2500.0, "frac_of_mfma_peak": flops / (pf_ms * 1e-3) / 1e12 / 2500.0,
+                   "check": {"vs": "the same prompt token by token through the decode path on the GPU", "max_abs_logit_diff": pf_err,
+                             "tolerance": pf_tol, "same_argmax": True},
                    "kernel": "k_gemm_f16 (mfma_f32_16x16x32_f16; 128x128x64 / 128x64x64 tiles, SiLU*up and fp16 epilogues fused) + batched "
                              "attention GEMMs" + ("" if args.quant == "f16" else "; per-block K-quant -> fp16 widening included")}
     else:
@@ -232,16 +261,20 @@ def run_single(args):
             a[1] += n
     # HBM traffic of the dominant kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
     # passes, gfx950 correction applied): collected offline on the same build, committed under profiles/
-    traffic = None
-    try:
-        if args.model == "llama-3.2-3b" and args.quant == "f16":
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))
-            traffic = pmc["kernels"]["nfai::k_gemv<1, 3, 2, 3, false, true>"]["hbm_bytes_per_launch"]
-        elif args.model == "llama-3.2-3b":
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic_q4km.json")))
-            traffic = pmc["kernels"]["nfai::k_gemv_kqt<112, 3, 1, true, 0>"]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        traffic = None
+    traffic, traffic_source = None, None
+    if args.model == "llama-3.2-3b":
+        tag = "" if args.quant == "f16" else "_q4km"
+        for rnd in ("round2", "round1"):  # newest committed PMC summary of this workload
+            f = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic{tag}.json")
+            try:
+                pmc = json.load(open(f))
+                k = pmc.get("dominant_kernel") or ("nfai::k_gemv<1, 3, 2, 3, false, true>" if args.quant == "f16" else "nfai::k_gemv_kqt<112, 3, 1, true, 0>")
+                traffic = pmc["kernels"][k]["hbm_bytes_per_launch"]
+                traffic_source = (f"profiles/{os.path.basename(f)}: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over `{pmc.get('command', '?')}`, "
+                                  "(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch; collected offline on this build, NOT in this run")
+                break
+            except (OSError, KeyError, ValueError):
+                continue
     gu_eager_ms = prof["gateup"][0] / max(1, prof["gateup"][1]) if prof else float("nan")
     # the dominant kernel's duration: its launches of one step (one per block, each streaming its own weights) replayed back
     # to back, 4 rounds, inside ONE event pair on the launch stream — what rocprofv3 --kernel-trace reports per launch (the
@@ -261,7 +294,7 @@ def run_single(args):
                    "positions": [pos0, pos0 + args.steps - 1], "kv_capacity": C, "parallelism": "single",
                    "graph": not args.no_graph},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": ("k_gemv<F16,GATEUP>" if args.quant == "f16" else "k_gemv_kqt<Q4_K_T16,GATEUP> int8-MFMA") + " (RMSNorm + Wgate/Wup GEMV + SiLU*up)",
                      "bytes_per_launch": dom_bytes, "us_per_launch": gu_ms * 1e3, "us_per_launch_eager_event_pair": gu_eager_ms * 1e3,
                      "timing": "hipEvents on the launch stream around 4 rounds of the kernel's launches of one step (one per block), back to back"},
@@ -283,6 +316,14 @@ def run_single(args):
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start one rank per GPU as a CHILD (never exec after the GPU was touched:
+        # nothing above initialises HIP) and leave with its exit code
+        import subprocess
+        port = os.environ.get("MASTER_PORT", "29517")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
     if args.gpus > 1 or world > 1:
         from nfai_amd.pipeline import run_bench_pipeline
         run_bench_pipeline(args)

@@ -40,6 +40,7 @@ extern "C" {
 typedef uint64_t nfai_ctx_t;
 typedef uint64_t nfai_buf_t;
 typedef uint64_t nfai_model_t;
+typedef uint64_t nfai_pp_t;
 
 enum nfai_status {
     NFAI_OK = 0,
@@ -152,6 +153,14 @@ int32_t nfai_hip_attn_decode(nfai_ctx_t ctx, nfai_buf_t q, nfai_buf_t kcache, nf
  * 5 / 6 / 7 = direct-to-LDS staging of 128x64 tiles with 2 / 3 / 4 stages. */
 int32_t nfai_hip_gemm_f16(nfai_ctx_t ctx, nfai_buf_t A_f16, nfai_buf_t W_f16, nfai_buf_t R, nfai_buf_t C, uint32_t M, uint32_t N,
                           uint32_t K, int32_t variant);
+/* nfai_hip_gemm_f16 with every epilogue and operand form the MFMA prefill launches (tests / tools; same reference member,
+ * MatrixMultiplyShader.cs:31-47 with inputRowCount = M): epi 0 fp32 (+R), 1 fp16, 2 fp16 = up * silu(gate) (SiLUShader.cs:121-123 +
+ * ElementWiseMultiplicationShader.cs:137 fused; W = gate rows, W1 = up rows, N = 2F, C is [M][N/2]); head-batched operands
+ * A [batch][M][K], W [batch / b_div][N][K], C [batch][M][N]; causal 1: C is a score matrix [t][s], tiles with only s > causal_pos0 + t
+ * are skipped (unwritten); causal 2: A is a probability matrix [t][s] (K = keys), K tiles past the last unmasked key are skipped. */
+int32_t nfai_hip_gemm_f16_ex(nfai_ctx_t ctx, nfai_buf_t A_f16, nfai_buf_t W_f16, nfai_buf_t W1_f16, nfai_buf_t R, nfai_buf_t C,
+                             uint32_t M, uint32_t N, uint32_t K, int32_t variant, int32_t epi, uint32_t batch, uint32_t b_div,
+                             uint32_t causal, uint32_t causal_pos0);
 /* The same batched product with W in Q4_K / Q6_K blocks (a buffer from nfai_hip_weight_upload with N %% 16 == 0 rows): the
  * dequant-in-LDS GEMM — quantised bytes -> registers -> fp16 tile in LDS -> MFMA; the weights are never widened in HBM. */
 int32_t nfai_hip_gemm_kq(nfai_ctx_t ctx, nfai_buf_t A_f16, nfai_buf_t W, int32_t w_type, nfai_buf_t R, nfai_buf_t C, uint32_t M,
@@ -202,6 +211,11 @@ int32_t nfai_hip_llama_set_tensor(nfai_model_t model, const char *name, int32_t 
 int32_t nfai_hip_llama_set_tensor_device(nfai_model_t model, const char *name, int32_t ggml_type,
                                          uint64_t n_rows, uint64_t n_cols, void *device_ptr);
 int32_t nfai_hip_llama_finalize(nfai_model_t model);
+/* Make `model` use the device-resident tensors `donor` already holds (same layer range, no copy, no second K-quant
+ * repack): the in-flight sequences (slots) of a pipeline stage are separate models — own KV cache and position — over ONE set
+ * of weights.  The reference aliases buffers the same way with ShaderProperty.BindShaderProprty (ShaderProperty.cs:95-108,
+ * no reference count): `donor` must outlive `model`.  Call before nfai_hip_llama_finalize(model). */
+int32_t nfai_hip_llama_share_tensors(nfai_model_t model, nfai_model_t donor);
 /* One token through embed -> blocks -> output_norm -> lm_head (LlamaModel.cs:116-125) at the
  * current position; logits_host (V floats) and argmax may be NULL.  Blocking. */
 int32_t nfai_hip_llama_decode_step(nfai_model_t model, uint32_t token, float *logits_host, uint32_t *argmax);
@@ -245,6 +259,24 @@ int32_t nfai_hip_llama_profile_step(nfai_model_t model, uint32_t token, float *m
  * are replayed back to back, `reps` rounds, between a single pair of hipEvents on the launch stream (decode launches are
  * idempotent).  This is the per-launch duration rocprofv3 --kernel-trace reports; bench.py's roofline uses it. */
 int32_t nfai_hip_llama_profile_kernel(nfai_model_t model, uint32_t token, int32_t kernel_class, uint32_t reps, float *us_avg);
+
+/* ---- layer pipeline across GPUs (no reference counterpart: the reference is single-device, it takes the last enumerated
+ *      Vulkan device, VulkanHelper.cs:149-150).  One process per GPU owns a contiguous range of TransformerBlocks (a slice of
+ *      the block loop LlamaModel.cs:118-121, nfai_llama_desc.layer_begin/end); between stages the hidden state (n_embd fp32)
+ *      moves point to point over RCCL/xGMI and the sampled token returns from the last stage to the first.  All operations
+ *      are enqueued on the context's stream, in order with nfai_hip_llama_stage_step; RCCL is bound with dlopen on first use
+ *      (NFAI_ERR_UNSUPPORTED when it is absent).  Operations that must progress together (one tick of the schedule) are
+ *      posted between _begin and _end (ncclGroupStart / ncclGroupEnd). ---- */
+int32_t nfai_hip_pp_unique_id(uint8_t *out128);   /* rank 0 creates it; the host hands the 128 bytes to every rank */
+int32_t nfai_hip_pp_init(nfai_ctx_t ctx, uint32_t rank, uint32_t world, const uint8_t *unique_id128, nfai_pp_t *out);
+int32_t nfai_hip_pp_destroy(nfai_pp_t pp);
+int32_t nfai_hip_pp_begin(nfai_pp_t pp);
+int32_t nfai_hip_pp_end(nfai_pp_t pp);
+int32_t nfai_hip_pp_send_hidden(nfai_pp_t pp, const void *hidden_dev, uint32_t n_floats, uint32_t peer);
+int32_t nfai_hip_pp_recv_hidden(nfai_pp_t pp, void *hidden_dev, uint32_t n_floats, uint32_t peer);
+int32_t nfai_hip_pp_send_token(nfai_pp_t pp, const void *token_dev, uint32_t peer);   /* one uint32 */
+int32_t nfai_hip_pp_recv_token(nfai_pp_t pp, void *token_dev, uint32_t peer);
+int32_t nfai_hip_pp_bcast_token(nfai_pp_t pp, void *token_dev, uint32_t root);        /* in place, every rank */
 
 #ifdef __cplusplus
 }

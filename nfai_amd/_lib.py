@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libnfai_hip.so")
+SO_PATH = os.environ.get("NFAI_HIP_LIB") or os.path.join(_HERE, "csrc", "libnfai_hip.so")  # NFAI_HIP_LIB: diagnostic builds (tools/)
 
 OK, ERR_INVALID, ERR_HIP, ERR_OOM, ERR_KV_FULL, ERR_UNSUPPORTED, ERR_STATE = range(7)
 F32, F16, Q4_K, Q6_K = 0, 1, 12, 14
@@ -65,6 +65,7 @@ SIGNATURES = {
     "nfai_hip_rmsnorm": [H, H, H, H, u32, f32],
     "nfai_hip_gemv": [H, H, i32, H, H, u64, u32, u32],
     "nfai_hip_gemm_f16": [H, H, H, H, H, u32, u32, u32, i32],
+    "nfai_hip_gemm_f16_ex": [H, H, H, H, H, H, u32, u32, u32, i32, i32, u32, u32, u32, u32],
     "nfai_hip_gemm_kq": [H, H, H, i32, H, H, u32, u32, u32],
     "nfai_hip_rope": [H, H, u64, H, u64, H, u32, u32, u32, u32],
     "nfai_hip_attn_scores": [H, H, H, H, u32, u32, u32, u32],
@@ -83,6 +84,7 @@ SIGNATURES = {
     "nfai_hip_llama_set_tensor": [H, C.c_char_p, i32, u64, u64, vp],
     "nfai_hip_llama_set_tensor_device": [H, C.c_char_p, i32, u64, u64, vp],
     "nfai_hip_llama_finalize": [H],
+    "nfai_hip_llama_share_tensors": [H, H],
     "nfai_hip_llama_decode_step": [H, u32, C.POINTER(f32), C.POINTER(u32)],
     "nfai_hip_llama_decode_greedy": [H, u32, u32, C.POINTER(u32)],
     "nfai_hip_llama_decode_enqueue": [H, u32],
@@ -100,6 +102,16 @@ SIGNATURES = {
     "nfai_hip_llama_bytes_per_token": [H, u32, C.POINTER(u64), C.POINTER(u64)],
     "nfai_hip_llama_profile_step": [H, u32, C.POINTER(f32), C.POINTER(u32)],
     "nfai_hip_llama_profile_kernel": [H, u32, i32, u32, C.POINTER(f32)],
+    "nfai_hip_pp_unique_id": [C.POINTER(C.c_uint8)],
+    "nfai_hip_pp_init": [H, u32, u32, C.POINTER(C.c_uint8), C.POINTER(H)],
+    "nfai_hip_pp_destroy": [H],
+    "nfai_hip_pp_begin": [H],
+    "nfai_hip_pp_end": [H],
+    "nfai_hip_pp_send_hidden": [H, vp, u32, u32],
+    "nfai_hip_pp_recv_hidden": [H, vp, u32, u32],
+    "nfai_hip_pp_send_token": [H, vp, u32],
+    "nfai_hip_pp_recv_token": [H, vp, u32],
+    "nfai_hip_pp_bcast_token": [H, vp, u32],
 }
 
 _lib = None

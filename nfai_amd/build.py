@@ -21,7 +21,7 @@ OUT = os.path.join(CSRC, "libnfai_hip.so")
 OBJ_DIR = os.path.join(CSRC, "build")
 ARCH = "gfx950"
 
-SOURCES = ["api.hip", "kernels_basic.hip", "kernels_gemv.hip", "kernels_gemv_kq.hip", "kernels_gemv_kqm.hip", "kernels_attn.hip", "kernels_prefill.hip", "llama.hip"]
+SOURCES = ["api.hip", "kernels_basic.hip", "kernels_gemv.hip", "kernels_gemv_kq.hip", "kernels_gemv_kqm.hip", "kernels_attn.hip", "kernels_prefill.hip", "llama.hip", "pp.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "nfai_hip.h")]
 
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=hidden", "-Wall",
@@ -44,7 +44,21 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, jobs: int | None = None, verbose: bool = False, extra_sources: list[str] | None = None) -> str:
+def build(force: bool = False, jobs: int | None = None, verbose: bool = False, extra_sources: list[str] | None = None,
+          stamps: bool = False) -> str:
+    """stamps=True builds the DIAGNOSTIC library libnfai_hip_stamps.so (-DNFAI_STAMPS: s_memrealtime readings inside the decode
+    kernels, tools/stamps.py); the product library never contains a stamp."""
+    global OUT, OBJ_DIR
+    if stamps:
+        out, obj_dir, flags = os.path.join(CSRC, "libnfai_hip_stamps.so"), os.path.join(CSRC, "build", "stamps"), ["-DNFAI_STAMPS"]
+        saved = (OUT, OBJ_DIR, list(CXXFLAGS))
+        OUT, OBJ_DIR = out, obj_dir
+        CXXFLAGS.extend(flags)
+        try:
+            return build(force, jobs, verbose, extra_sources)
+        finally:
+            OUT, OBJ_DIR = saved[0], saved[1]
+            CXXFLAGS[:] = saved[2]
     os.makedirs(OBJ_DIR, exist_ok=True)
     cc = hipcc()
     sources = SOURCES + [s for s in (extra_sources or []) if s not in SOURCES]
@@ -84,5 +98,6 @@ if __name__ == "__main__":
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=None)
     ap.add_argument("-v", "--verbose", action="store_true")
+    ap.add_argument("--stamps", action="store_true", help="build the diagnostic libnfai_hip_stamps.so instead")
     a = ap.parse_args()
-    print(build(a.force, a.jobs, a.verbose))
+    print(build(a.force, a.jobs, a.verbose, stamps=a.stamps))

@@ -55,6 +55,21 @@ bool handle_live(uint64_t h)
     return g_handles.count(h) != 0;
 }
 
+#ifdef NFAI_STAMPS
+// Diagnostic build: launch slots of the stamp buffer in launch order (the tool installs the buffer, runs, reads it back).
+static unsigned long long *g_stamp_buf = nullptr;
+static uint32_t g_stamp_slots = 0, g_stamp_next = 0;
+static StampSlot g_stamp_info[4096];
+unsigned long long *stamp_next_slot(const char *name, uint32_t grid, uint32_t block)
+{
+    if (!g_stamp_buf || g_stamp_next >= g_stamp_slots || g_stamp_next >= 4096) return nullptr;
+    StampSlot &si = g_stamp_info[g_stamp_next];
+    snprintf(si.name, sizeof(si.name), "%s", name);
+    si.grid = grid; si.block = block;
+    return g_stamp_buf + (size_t)(g_stamp_next++) * STAMP_WAVES * STAMP_WORDS;
+}
+#endif
+
 Ctx *ctx_of(nfai_ctx_t h)
 {
     if (!handle_live(h)) return nullptr;
@@ -600,6 +615,45 @@ NFAI_API int32_t nfai_hip_gemm_f16(nfai_ctx_t h, nfai_buf_t A, nfai_buf_t W, nfa
     return NFAI_OK;
 }
 
+// Extended form of nfai_hip_gemm_f16 for tests and tools: every epilogue (fp32 + residual, fp16, SiLU*up fp16), head-batched
+// operands (batch, b_div) and the causal tile skipping of the attention GEMMs — the configurations the MFMA prefill launches.
+//   A [batch][M][K] fp16;  W [batch / b_div][N][K] fp16 (epi 2: W = gate [N/2][K], W1 = up [N/2][K], batch 1);
+//   C [batch][M][N] fp32 (epi 0) / fp16 (epi 1), [M][N/2] fp16 (epi 2);  R as C (epi 0 only).
+NFAI_API int32_t nfai_hip_gemm_f16_ex(nfai_ctx_t h, nfai_buf_t A, nfai_buf_t W, nfai_buf_t W1, nfai_buf_t R, nfai_buf_t C, uint32_t M,
+                                      uint32_t N, uint32_t K, int32_t variant, int32_t epi, uint32_t batch, uint32_t b_div,
+                                      uint32_t causal, uint32_t causal_pos0)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(ba, A);
+    BUF_OR_FAIL(bw, W);
+    BUF_OR_FAIL(bc, C);
+    Buf *br = R ? buf_of(R) : nullptr, *bw1 = W1 ? buf_of(W1) : nullptr;
+    if ((R && !br) || (W1 && !bw1)) return fail(NFAI_ERR_INVALID, "gemm_f16_ex: invalid residual / second weight handle");
+    if (M == 0 || N % 64 || K % 64 || K == 0 || batch == 0 || b_div == 0 || batch % b_div || epi < 0 || epi > 2 || causal > 2)
+        return fail(NFAI_ERR_INVALID, "gemm_f16_ex: bad shape (M=%u N=%u K=%u batch=%u b_div=%u epi=%d causal=%u)", M, N, K, batch, b_div, epi, causal);
+    if (epi == 2 && (!bw1 || batch != 1 || br)) return fail(NFAI_ERR_INVALID, "gemm_f16_ex: the SiLU*up epilogue takes gate and up matrices, batch 1, no residual");
+    if (epi == 1 && br) return fail(NFAI_ERR_INVALID, "gemm_f16_ex: the fp16 epilogue takes no residual");
+    const uint64_t nw = epi == 2 ? N / 2 : N;
+    NEED(ba, (uint64_t)batch * M * K, 2);
+    NEED(bw, (uint64_t)(batch / b_div) * nw * K, 2);
+    if (bw1) NEED(bw1, nw * K, 2);
+    NEED(bc, (uint64_t)batch * M * nw, epi == 0 ? 4 : 2);
+    if (br) NEED(br, (uint64_t)batch * M * N, 4);
+    GemmArgs g;
+    g.A = ba->ptr; g.lda = K; g.a_bs = (uint64_t)M * K;
+    g.B = bw->ptr; g.ldb = K; g.b_bs = (uint64_t)N * K; g.b_div = b_div;
+    if (epi == 2) { g.B1 = bw1->ptr; g.n0 = N / 2; }
+    g.C = bc->ptr; g.ldc = (uint32_t)nw; g.c_bs = (uint64_t)M * nw; g.epi = epi;
+    g.R = br ? static_cast<const float *>(br->ptr) : nullptr;
+    g.M = M; g.N = N; g.K = K; g.batch = batch; g.variant = variant;
+    g.causal = causal; g.causal_pos0 = causal_pos0;
+    g.n_cu = (uint32_t)c->prop.multiProcessorCount;
+    hipError_t e = launch_gemm_f16(g, c->stream);
+    if (e == hipErrorInvalidValue) return fail(NFAI_ERR_INVALID, "gemm_f16_ex: unsupported shape / variant %d (M=%u N=%u K=%u epi=%d)", variant, M, N, K, epi);
+    if (e != hipSuccess) return fail(NFAI_ERR_HIP, "gemm_f16_ex: launch failed: %s", hipGetErrorString(e));
+    return NFAI_OK;
+}
+
 NFAI_API int32_t nfai_hip_gemm_kq(nfai_ctx_t h, nfai_buf_t A, nfai_buf_t W, int32_t type, nfai_buf_t R, nfai_buf_t C, uint32_t M, uint32_t N,
                                   uint32_t K)
 {
@@ -754,3 +808,23 @@ NFAI_API int32_t nfai_hip_gemv_qkv_rope(nfai_ctx_t h, nfai_buf_t Wq, nfai_buf_t 
     a.pos_dev = scratch_pos(c);
     return gemv_common(c, a, __func__);
 }
+
+#ifdef NFAI_STAMPS
+// Not part of include/nfai_hip.h: exists only in libnfai_hip_stamps.so (tools/stamps.py binds it by name).
+NFAI_API int32_t nfai_hip_debug_stamps_install(void *buf, uint32_t n_slots)
+{
+    nfai::g_stamp_buf = static_cast<unsigned long long *>(buf);
+    nfai::g_stamp_slots = n_slots;
+    nfai::g_stamp_next = 0;
+    return NFAI_OK;
+}
+NFAI_API int32_t nfai_hip_debug_stamps_info(uint32_t slot, char *name48, uint32_t *grid, uint32_t *block, uint32_t *n_used)
+{
+    if (n_used) *n_used = nfai::g_stamp_next;
+    if (slot >= nfai::g_stamp_next) return NFAI_ERR_INVALID;
+    memcpy(name48, nfai::g_stamp_info[slot].name, 48);
+    *grid = nfai::g_stamp_info[slot].grid;
+    *block = nfai::g_stamp_info[slot].block;
+    return NFAI_OK;
+}
+#endif

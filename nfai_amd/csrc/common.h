@@ -30,6 +30,20 @@ int fail(int code, const char *fmt, ...);
         if (!(cond)) return nfai::fail(NFAI_ERR_INVALID, __VA_ARGS__); \
     } while (0)
 
+// ---- in-kernel time stamps (diagnostic build only: python -m nfai_amd.build --stamps -> libnfai_hip_stamps.so) -------------
+// Every wave of a stamped kernel records up to 8 readings of s_memrealtime (100 MHz, one clock for the whole chip) into its
+// launch's slot of a buffer the tool hands in; no stamp exists in the product build (MI355X guide, "In-kernel stamps").
+#ifdef NFAI_STAMPS
+constexpr uint32_t STAMP_WAVES = 2048, STAMP_WORDS = 8;
+struct StampSlot { char name[48]; uint32_t grid, block; };
+unsigned long long *stamp_next_slot(const char *name, uint32_t grid, uint32_t block);  // null when no buffer is installed
+#define NFAI_STAMP_PARAM unsigned long long *stamps;
+#define NFAI_STAMP_SET(p, name, grid, block) (p).stamps = nfai::stamp_next_slot(name, grid, block)
+#else
+#define NFAI_STAMP_PARAM
+#define NFAI_STAMP_SET(p, name, grid, block) ((void)0)
+#endif
+
 // ---- handles --------------------------------------------------------------------------------
 struct Ctx {
     uint32_t magic = 0x4E464358;  // 'NFCX'
@@ -267,6 +281,27 @@ __device__ __forceinline__ float dot8_f16(u32x4 w, f32x4 x0, f32x4 x1, float acc
     acc = fmaf(h2f_hi(w[3]), x1[3], acc);
     return acc;
 }
+
+#ifdef NFAI_STAMPS
+// STAMP(i): reading i of this wave (wave-uniform scalar registers; written out by stamp_flush at the end of the kernel)
+struct Stamps {
+    unsigned long long t[STAMP_WORDS];
+    __device__ __forceinline__ void at(int i) { __builtin_amdgcn_sched_barrier(0); t[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); }
+    __device__ __forceinline__ void flush(unsigned long long *base, uint32_t wave_global, int n)
+    {
+        if (!base || wave_global >= STAMP_WAVES) return;
+        if ((threadIdx.x & 63) == 0)
+            for (int i = 0; i < n; i++) base[(size_t)wave_global * STAMP_WORDS + i] = t[i];
+    }
+};
+#define STAMP_DECL nfai::Stamps _st
+#define STAMP(i) _st.at(i)
+#define STAMP_FLUSH(base, wg, n) _st.flush(base, wg, n)
+#else
+#define STAMP_DECL
+#define STAMP(i) ((void)0)
+#define STAMP_FLUSH(base, wg, n) ((void)0)
+#endif
 
 __device__ __forceinline__ float silu_ref(float x)
 {

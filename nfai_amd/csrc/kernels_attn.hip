@@ -43,6 +43,7 @@ struct AttnParams {
     uint32_t H, Hkv, D;
     const uint32_t *pos;
     uint32_t min_chunk, max_split;  // slicing policy (defaults ATTN_MIN_CHUNK / ATTN_NSPLIT_MAX; env-tunable for sweeps)
+    NFAI_STAMP_PARAM
 };
 
 __device__ __forceinline__ void attn_split(uint32_t S, uint32_t min_chunk, uint32_t max_split, uint32_t &nsplit, uint32_t &chunk)
@@ -104,6 +105,11 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
     attn_split(S, p.min_chunk, p.max_split, nsplit, chunk);
     const uint32_t kvh = blockIdx.x, split = blockIdx.y;
     if (split >= nsplit) return;
+    STAMP_DECL;
+    STAMP(0);
+#ifdef NFAI_STAMPS
+    const uint32_t stamp_wave = (blockIdx.y * gridDim.x + blockIdx.x) * (ATTN_BLOCK / 64) + (threadIdx.x >> 6);
+#endif
     const uint32_t t0 = split * chunk, t1 = min(t0 + chunk, S), n = t1 - t0;
 
     float *stat = smem;               // [G][2] = (slice max, slice sum of exp); [32] = last-block flag
@@ -126,6 +132,7 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
         qv[g] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(
             (const __attribute__((address_space(1))) float *)p.q + (uint64_t)(kvh * G + g) * D + li * 4);
     const float scale = 1.0f / sqrtf((float)D);  // …ScoreCalculationShader.cs:93
+    STAMP(1);  // first K rows, V rows and q requested
 
     f32x4 acc[G];
 #pragma unroll
@@ -260,6 +267,7 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
         if (niter == 1) scores(kx, 0);
         else pipe(std::integral_constant<int, 2>{}, p.kc, kx, scores);
         __syncthreads();
+        STAMP(2);  // scores of the slice in LDS
 
         // ---- phase 2: slice max, exp, sum (AttentionSoftmaxShader.cs:148-169 on the slice) -----------
         for (uint32_t g = tid >> 6; g < (uint32_t)G; g += ATTN_BLOCK / 64) {  // wave per query head
@@ -276,6 +284,7 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
             if (lane == 0) { stat[g * 2] = m; stat[g * 2 + 1] = sum; }
         }
         __syncthreads();
+        STAMP(3);  // slice softmax done
 
         // ---- phase 3: weighted V sum over the slice ---------------------------------------------
         auto weigh = [&](const f32x4 (&r)[PF], uint32_t it) {
@@ -314,20 +323,23 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
             st_agent(my_part + g * (D + 2) + d, sum);
         }
     }
-    if (nsplit == 1) return;
+    if (nsplit == 1) { STAMP_FLUSH(p.stamps, stamp_wave, 4); return; }
     if (tid < (uint32_t)G) {
         st_agent(my_part + tid * (D + 2) + D, stat[tid * 2]);
         st_agent(my_part + tid * (D + 2) + D + 1, stat[tid * 2 + 1]);
     }
     // ---- hand-off: drain every storing wave, barrier, one ticket per block --------------------
+    STAMP(4);  // V phase, LDS reduction, partial stores issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    STAMP(5);  // every wave's partial stores acknowledged
     if (tid == 0) {
         const uint32_t t = __hip_atomic_fetch_add(&p.tickets[kvh], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         stat[32] = (t == nsplit - 1) ? 1.0f : 0.0f;
     }
     __syncthreads();
-    if (stat[32] == 0.0f) return;
+    STAMP(6);  // ticket drawn
+    if (stat[32] == 0.0f) { STAMP_FLUSH(p.stamps, stamp_wave, 7); return; }
 
     // ---- merge by the last block of this kv head: slices in fixed order 0..nsplit-1 --------------
     const float *base = p.partials + (uint64_t)kvh * ATTN_NSPLIT_MAX * G * (D + 2);
@@ -367,6 +379,11 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
         }
     }
     if (tid == 0) __hip_atomic_store(&p.tickets[kvh], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+#ifdef NFAI_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(7);  // merge done and stored (last block of the kv head only)
+    STAMP_FLUSH(p.stamps, stamp_wave, 8);
+#endif
 }
 
 size_t attn_partials_bytes(uint32_t H, uint32_t Hkv, uint32_t D)
@@ -421,6 +438,7 @@ hipError_t launch_attn_decode(const AttnArgs &a, hipStream_t s)
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     const dim3 grid(a.Hkv, p.max_split);
     const bool f16 = a.kv_type == NFAI_F16;
+    NFAI_STAMP_SET(p, "attn_decode", a.Hkv * p.max_split, ATTN_BLOCK);
     // One-pass (online softmax, v_exp_f32) or two-pass form.  The position is device-side, so the choice is made from the KV
     // capacity the model was created with: above 2048 positions the one-pass form (8192 positions: 520 vs 493 tokens/s at
     // 3B), otherwise the two-pass form, which mirrors the reference's three dispatches literally (max, exp(clamp), sum with

@@ -39,6 +39,7 @@ struct GemvParams {
     const uint32_t *pos;
     int kv_f16;
     uint32_t prefetch_only;  // 1: touch the first two steps of every wave's weights (default cache policy) and exit
+    NFAI_STAMP_PARAM
 };
 
 #define GLOBAL_AS __attribute__((address_space(1)))
@@ -201,6 +202,8 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
     const uint32_t cpg = p.KC / U;  // K-chunk groups per unit group
     const uint32_t nsteps = ngroups * cpg;
     const uint32_t kpad = p.KC * 64 * EPL;
+    STAMP_DECL;
+    STAMP(0);  // wave started
 
     // ---- prefetch-only launch (runs on a side stream while the PREVIOUS kernel of the token is still
     //      streaming): request exactly the bytes this kernel's waves will ask for first, with the
@@ -266,6 +269,7 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
     // compiler's vmcnt bookkeeping take the worst path and wait for the weights before using x
     issue(bufA);
     issue(bufB);
+    STAMP(1);  // activation loads and the first two weight steps issued
 
     // ---- (3) prologue: x (optionally RMSNorm'd: RMSNormShader.cs:136-149) -> LDS ---------------
     {
@@ -301,6 +305,7 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
         }
         __syncthreads();
     }
+    STAMP(2);  // x (normalised) is in LDS
 
     float acc[R];
 #pragma unroll
@@ -336,6 +341,18 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
     //      Refills inside the loop are unconditional so every wait is an exact count; the last
     //      one to three steps are peeled.
     uint32_t st = 0;
+#ifdef NFAI_STAMPS
+    if (nsteps > 4) {  // first step on its own so that "first weights landed and multiplied" gets a stamp (same order of work)
+        consume(bufA);
+        STAMP(3);
+        issue(bufA);
+        consume(bufB);
+        issue(bufB);
+        st = 2;
+    } else {
+        STAMP(3);
+    }
+#endif
     for (; st + 3 < nsteps; st += 2) {
         consume(bufA);
         issue(bufA);
@@ -354,6 +371,12 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
     } else if (rem == 1) {
         consume(bufA);
     }
+#ifdef NFAI_STAMPS
+    STAMP(4);  // last FMA, reduction and epilogue stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(5);  // stores acknowledged
+    STAMP_FLUSH(p.stamps, gw, 6);
+#endif
 }
 
 // ---- host side: shape checks and the (waves per block, units per wave step, K unroll) choice ----
@@ -498,6 +521,10 @@ hipError_t launch_gemv(const GemvArgs &a, hipStream_t s)
     if (!pl.ok) return hipErrorInvalidValue;
     p.KC = (a.K + 64 * epl - 1) / (64 * epl);
     if (pl.lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    {
+        static const char *names[] = {"gemv_plain", "gemv_residual", "gemv_qkv_rope", "gemv_gateup"};
+        NFAI_STAMP_SET(p, names[a.mode & 3], pl.grid, pl.block);
+    }
     if (a.w_type == NFAI_F16) return dispatch_mode<NFAI_F16>(p, pl, a.mode, s);
     return dispatch_mode<NFAI_F32>(p, pl, a.mode, s);
 }

@@ -637,37 +637,81 @@ static int set_tensor_impl(Model *m, const char *name, int type, uint64_t rows, 
     if (rb == 0) return fail(NFAI_ERR_UNSUPPORTED, "set_tensor(%s): ggml type %d with %llu columns is not supported (the reference "
                              "throws \"Unsupported data type\" for everything but F32/F16, Parser.cs:111-114)", name, type,
                              (unsigned long long)cols);
-    if (t->owned && t->ptr) { HIP_TRY(hipFree(t->ptr)); }
-    t->type = type; t->rows = rows; t->cols = cols; t->bytes = rb * rows;
+    if (!dev && !host) return fail(NFAI_ERR_INVALID, "set_tensor(%s): null data", name);
+    if (dev && (reinterpret_cast<uintptr_t>(dev) & 15)) return fail(NFAI_ERR_INVALID, "set_tensor_device(%s): pointer not 16-byte aligned", name);
+    // The new storage is built completely before the slot is touched: a failing re-set (allocation, copy, repack) leaves the
+    // previous tensor in place and valid.  Only then is the old owned storage freed and the slot swapped.
+    Tensor nt;
+    nt.type = type; nt.rows = rows; nt.cols = cols; nt.bytes = rb * rows;
+    hipStream_t s = m->ctx->stream;
     const bool q4_t16 = type == NFAI_Q4_K && rows > 0 && rows % 16 == 0, q6_t16 = type == NFAI_Q6_K && rows > 0 && rows % 16 == 0;
+    auto fail_free = [&](void *a, void *b, int rc) { if (a) hipFree(a); if (b) hipFree(b); return rc; };
     if (type == NFAI_Q6_K || q4_t16) {
-        // native blocks (host or device) -> owned repacked copy: Q6_K planes (common.h), Q4_K T16 tiles (kernels_gemv_kqm.hip)
-        void *native = dev;
+        // native blocks (host or device) -> owned repacked copy: Q6_K planes (common.h), Q4_K / Q6_K T16 tiles (kernels_gemv_kqm.hip)
+        void *native = dev, *staged = nullptr;
         if (!dev) {
-            if (!host) return fail(NFAI_ERR_INVALID, "set_tensor(%s): null data", name);
-            DALLOC(native, t->bytes);
-            HIP_TRY(hipMemcpyAsync(native, host, t->bytes, hipMemcpyHostToDevice, m->ctx->stream));
+            int rc = dalloc(&staged, nt.bytes, s);
+            if (rc) return rc;
+            hipError_t e = hipMemcpyAsync(staged, host, nt.bytes, hipMemcpyHostToDevice, s);
+            if (e != hipSuccess) return fail_free(staged, nullptr, fail(NFAI_ERR_HIP, "set_tensor(%s): upload failed: %s", name, hipGetErrorString(e)));
+            native = staged;
         }
-        DALLOC(t->ptr, t->bytes);
-        t->owned = true;
-        hipError_t e = q4_t16 ? launch_repack_q4k_t16(native, t->ptr, rows, cols, m->ctx->stream)
-                     : q6_t16 ? launch_repack_q6k_t16(native, t->ptr, rows, cols, m->ctx->stream)
-                              : launch_repack_q6k(native, t->ptr, rows * cols / 256, m->ctx->stream);
-        if (e != hipSuccess) return fail(NFAI_ERR_HIP, "set_tensor(%s): K-quant repack failed: %s", name, hipGetErrorString(e));
-        if (q4_t16) t->type = NFAI_Q4_K_T16;
-        if (q6_t16) t->type = NFAI_Q6_K_T16;
-        HIP_TRY(hipStreamSynchronize(m->ctx->stream));
-        if (!dev) HIP_TRY(hipFree(native));
+        int rc = dalloc(&nt.ptr, nt.bytes, s);
+        if (rc) return fail_free(staged, nullptr, rc);
+        nt.owned = true;
+        hipError_t e = q4_t16 ? launch_repack_q4k_t16(native, nt.ptr, rows, cols, s)
+                     : q6_t16 ? launch_repack_q6k_t16(native, nt.ptr, rows, cols, s)
+                              : launch_repack_q6k(native, nt.ptr, rows * cols / 256, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return fail_free(staged, nt.ptr, fail(NFAI_ERR_HIP, "set_tensor(%s): K-quant repack failed: %s", name, hipGetErrorString(e)));
+        if (q4_t16) nt.type = NFAI_Q4_K_T16;
+        if (q6_t16) nt.type = NFAI_Q6_K_T16;
+        if (staged) hipFree(staged);
     } else if (dev) {
-        if (reinterpret_cast<uintptr_t>(dev) & 15) return fail(NFAI_ERR_INVALID, "set_tensor_device(%s): pointer not 16-byte aligned", name);
-        t->ptr = dev;
-        t->owned = false;
+        nt.ptr = dev;
+        nt.owned = false;
     } else {
-        if (!host) return fail(NFAI_ERR_INVALID, "set_tensor(%s): null data", name);
-        DALLOC(t->ptr, t->bytes);
-        t->owned = true;
-        HIP_TRY(hipMemcpyAsync(t->ptr, host, t->bytes, hipMemcpyHostToDevice, m->ctx->stream));
-        HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+        int rc = dalloc(&nt.ptr, nt.bytes, s);
+        if (rc) return rc;
+        nt.owned = true;
+        hipError_t e = hipMemcpyAsync(nt.ptr, host, nt.bytes, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return fail_free(nt.ptr, nullptr, fail(NFAI_ERR_HIP, "set_tensor(%s): upload failed: %s", name, hipGetErrorString(e)));
+    }
+    m->finalized = false;  // graphs captured over the old pointer are dropped by the next finalize
+    if (t->owned && t->ptr) {
+        hipStreamSynchronize(s);  // nothing enqueued may still read the old storage
+        hipFree(t->ptr);
+    }
+    *t = nt;
+    return NFAI_OK;
+}
+
+// The slots of a pipeline stage: separate models (KV cache, position, graph) over the donor's weights.
+NFAI_API int32_t nfai_hip_llama_share_tensors(nfai_model_t h, nfai_model_t donor_h)
+{
+    MODEL_OR_FAIL(m, h);
+    Model *src = model_of(donor_h);
+    if (!src || src == m) return fail(NFAI_ERR_INVALID, "share_tensors: invalid donor handle");
+    if (src->ctx->device != m->ctx->device) return fail(NFAI_ERR_INVALID, "share_tensors: donor lives on another device");
+    const nfai_llama_desc &a = m->d, &b = src->d;
+    if (a.E != b.E || a.L != b.L || a.H != b.H || a.Hkv != b.Hkv || a.D != b.D || a.F != b.F || a.V != b.V ||
+        a.layer_begin != b.layer_begin || a.layer_end != b.layer_end)
+        return fail(NFAI_ERR_INVALID, "share_tensors: donor has different dimensions or layer range");
+    auto share = [](Tensor &dst, const Tensor &s2) {
+        if (dst.owned && dst.ptr) hipFree(dst.ptr);
+        dst = s2;
+        dst.owned = false;
+    };
+    hipStreamSynchronize(m->ctx->stream);
+    share(m->token_embd, src->token_embd);
+    share(m->output_norm, src->output_norm);
+    share(m->output, src->output);
+    for (size_t i = 0; i < m->layers.size(); i++) {
+        Layer &L = m->layers[i];
+        const Layer &S = src->layers[i];
+        share(L.attn_norm, S.attn_norm); share(L.wq, S.wq); share(L.wk, S.wk); share(L.wv, S.wv); share(L.wo, S.wo);
+        share(L.ffn_norm, S.ffn_norm); share(L.wgate, S.wgate); share(L.wup, S.wup); share(L.wdown, S.wdown);
     }
     m->finalized = false;
     return NFAI_OK;

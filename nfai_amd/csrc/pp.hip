@@ -1,0 +1,214 @@
+// pp.hip — the layer pipeline's exchange step behind the C ABI (SURVEY.md §8b "pp" group, §8e).
+//
+// The reference is single-device (it takes the last enumerated Vulkan device, VulkanHelper.cs:149-150) and has no
+// exchange step of any kind; these entry points are what a multi-GPU NFAI host (one process per GPU, each owning a
+// contiguous range of TransformerBlocks = a slice of the block loop LlamaModel.cs:118-121) calls between stages:
+// the hidden state (n_embd fp32) moves to the next stage and the sampled token id returns from the last stage to
+// the first, point to point over RCCL/xGMI.  There is no collective on the data path.
+//
+// Every operation is ENQUEUED on the context's stream (the stream the stage's hipGraph runs on), so a tick is
+// [stage graph] -> [group of sends / receives] with no host synchronisation.  RCCL is bound at run time with dlopen
+// (the library that is already mapped in the process is preferred, e.g. the one PyTorch ships): libnfai_hip.so has no
+// link-time dependency on it and single-GPU hosts never load it.
+#include <dlfcn.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "common.h"
+
+using namespace nfai;
+
+namespace {
+
+// the few RCCL declarations used (rccl.h: ncclUniqueId :43, ncclCommInitRank :220, ncclSend :700, ncclRecv :722,
+// ncclBroadcast :591, ncclGroupStart :923); types restated so the build does not need the header
+typedef struct { char internal[128]; } UniqueId;
+typedef void *Comm;
+typedef int Result;                      // ncclSuccess == 0
+enum { DT_UINT32 = 3, DT_FLOAT32 = 7 };  // ncclUint32, ncclFloat32
+
+struct Rccl {
+    void *so = nullptr;
+    Result (*GetUniqueId)(UniqueId *) = nullptr;
+    Result (*CommInitRank)(Comm *, int, UniqueId, int) = nullptr;
+    Result (*CommDestroy)(Comm) = nullptr;
+    Result (*Send)(const void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+    Result (*Recv)(void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+    Result (*Broadcast)(const void *, void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+    Result (*GroupStart)() = nullptr;
+    Result (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(Result) = nullptr;
+    std::string why;
+};
+
+Rccl *rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so", "librccl.so.1"};
+        for (const char *n : names)  // a copy already mapped in this process first (PyTorch ships its own)
+            if (!r.so) r.so = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        if (const char *env = getenv("NFAI_RCCL_PATH"))
+            if (!r.so) r.so = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+        for (const char *n : names)
+            if (!r.so) r.so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!r.so) r.so = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!r.so) { r.why = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return; }
+#define SYM(field, name)                                                        \
+    r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.so, name));           \
+    if (!r.field) { r.why = std::string("RCCL symbol missing: ") + name; return; }
+        SYM(GetUniqueId, "ncclGetUniqueId")
+        SYM(CommInitRank, "ncclCommInitRank")
+        SYM(CommDestroy, "ncclCommDestroy")
+        SYM(Send, "ncclSend")
+        SYM(Recv, "ncclRecv")
+        SYM(Broadcast, "ncclBroadcast")
+        SYM(GroupStart, "ncclGroupStart")
+        SYM(GroupEnd, "ncclGroupEnd")
+        SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    });
+    return &r;
+}
+
+struct Pp {
+    uint32_t magic = 0x4E465050;  // 'NFPP'
+    Ctx *ctx = nullptr;
+    Comm comm = nullptr;
+    uint32_t rank = 0, world = 1;
+    bool in_group = false;
+};
+
+Pp *pp_of(nfai_pp_t h)
+{
+    if (!handle_live(h)) return nullptr;
+    Pp *p = reinterpret_cast<Pp *>(h);
+    return p->magic == 0x4E465050 ? p : nullptr;
+}
+
+#define RCCL_OR_FAIL(r)                                                                   \
+    Rccl *r = rccl();                                                                     \
+    if (!r->why.empty()) return fail(NFAI_ERR_UNSUPPORTED, "%s: %s", __func__, r->why.c_str())
+
+#define PP_OR_FAIL(p, h)                                                                  \
+    Pp *p = pp_of(h);                                                                     \
+    if (!p) return fail(NFAI_ERR_INVALID, "%s: invalid pipeline handle", __func__);       \
+    HIP_TRY(hipSetDevice(p->ctx->device))
+
+#define NCCL_TRY(r, expr)                                                                 \
+    do {                                                                                  \
+        Result _e = (expr);                                                               \
+        if (_e != 0) return fail(NFAI_ERR_HIP, "%s: %s failed: %s", __func__, #expr, r->GetErrorString(_e)); \
+    } while (0)
+
+}  // namespace
+
+NFAI_API int32_t nfai_hip_pp_unique_id(uint8_t *out128)
+{
+    if (!out128) return fail(NFAI_ERR_INVALID, "pp_unique_id: null output");
+    RCCL_OR_FAIL(r);
+    UniqueId id;
+    NCCL_TRY(r, r->GetUniqueId(&id));
+    memcpy(out128, id.internal, 128);
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_pp_init(nfai_ctx_t ch, uint32_t rank, uint32_t world, const uint8_t *id128, nfai_pp_t *out)
+{
+    Ctx *c = ctx_of(ch);
+    if (!c) return fail(NFAI_ERR_INVALID, "pp_init: invalid context handle");
+    if (!id128 || !out || world == 0 || rank >= world) return fail(NFAI_ERR_INVALID, "pp_init: bad arguments (rank %u of %u)", rank, world);
+    HIP_TRY(hipSetDevice(c->device));
+    RCCL_OR_FAIL(r);
+    UniqueId id;
+    memcpy(id.internal, id128, 128);
+    Pp *p = new Pp();
+    p->ctx = c; p->rank = rank; p->world = world;
+    Result e = r->CommInitRank(&p->comm, (int)world, id, (int)rank);
+    if (e != 0) { delete p; return fail(NFAI_ERR_HIP, "pp_init: ncclCommInitRank(rank %u of %u) failed: %s", rank, world, r->GetErrorString(e)); }
+    handle_register(p);
+    *out = reinterpret_cast<nfai_pp_t>(p);
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_pp_destroy(nfai_pp_t h)
+{
+    PP_OR_FAIL(p, h);
+    RCCL_OR_FAIL(r);
+    hipStreamSynchronize(p->ctx->stream);
+    if (p->comm) r->CommDestroy(p->comm);
+    p->magic = 0;
+    handle_unregister(p);
+    delete p;
+    return NFAI_OK;
+}
+
+// One tick's operations are posted between begin and end (ncclGroupStart / ncclGroupEnd): both ends of every link post in the
+// same tick, so a send that only completes against its matching receive cannot deadlock the schedule.
+NFAI_API int32_t nfai_hip_pp_begin(nfai_pp_t h)
+{
+    PP_OR_FAIL(p, h);
+    RCCL_OR_FAIL(r);
+    if (p->in_group) return fail(NFAI_ERR_STATE, "pp_begin: a group is already open");
+    NCCL_TRY(r, r->GroupStart());
+    p->in_group = true;
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_pp_end(nfai_pp_t h)
+{
+    PP_OR_FAIL(p, h);
+    RCCL_OR_FAIL(r);
+    if (!p->in_group) return fail(NFAI_ERR_STATE, "pp_end: no open group");
+    p->in_group = false;
+    NCCL_TRY(r, r->GroupEnd());
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_pp_send_hidden(nfai_pp_t h, const void *hidden_dev, uint32_t n_floats, uint32_t peer)
+{
+    PP_OR_FAIL(p, h);
+    RCCL_OR_FAIL(r);
+    if (!hidden_dev || n_floats == 0 || peer >= p->world) return fail(NFAI_ERR_INVALID, "pp_send_hidden: bad arguments (peer %u of %u)", peer, p->world);
+    NCCL_TRY(r, r->Send(hidden_dev, n_floats, DT_FLOAT32, (int)peer, p->comm, p->ctx->stream));
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_pp_recv_hidden(nfai_pp_t h, void *hidden_dev, uint32_t n_floats, uint32_t peer)
+{
+    PP_OR_FAIL(p, h);
+    RCCL_OR_FAIL(r);
+    if (!hidden_dev || n_floats == 0 || peer >= p->world) return fail(NFAI_ERR_INVALID, "pp_recv_hidden: bad arguments (peer %u of %u)", peer, p->world);
+    NCCL_TRY(r, r->Recv(hidden_dev, n_floats, DT_FLOAT32, (int)peer, p->comm, p->ctx->stream));
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_pp_send_token(nfai_pp_t h, const void *token_dev, uint32_t peer)
+{
+    PP_OR_FAIL(p, h);
+    RCCL_OR_FAIL(r);
+    if (!token_dev || peer >= p->world) return fail(NFAI_ERR_INVALID, "pp_send_token: bad arguments");
+    NCCL_TRY(r, r->Send(token_dev, 1, DT_UINT32, (int)peer, p->comm, p->ctx->stream));
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_pp_recv_token(nfai_pp_t h, void *token_dev, uint32_t peer)
+{
+    PP_OR_FAIL(p, h);
+    RCCL_OR_FAIL(r);
+    if (!token_dev || peer >= p->world) return fail(NFAI_ERR_INVALID, "pp_recv_token: bad arguments");
+    NCCL_TRY(r, r->Recv(token_dev, 1, DT_UINT32, (int)peer, p->comm, p->ctx->stream));
+    return NFAI_OK;
+}
+
+// The sampled token of the last stage made visible to every stage (a host that keeps one chat transcript per rank).
+NFAI_API int32_t nfai_hip_pp_bcast_token(nfai_pp_t h, void *token_dev, uint32_t root)
+{
+    PP_OR_FAIL(p, h);
+    RCCL_OR_FAIL(r);
+    if (!token_dev || root >= p->world) return fail(NFAI_ERR_INVALID, "pp_bcast_token: bad arguments");
+    NCCL_TRY(r, r->Broadcast(token_dev, token_dev, 1, DT_UINT32, (int)root, p->comm, p->ctx->stream));
+    return NFAI_OK;
+}

@@ -90,7 +90,8 @@ class LlamaModel:
     def __init__(self, mgr: HipBufferManager, metadata: dict, tensors: dict, contextSize: int = 1024, *,
                  tokenizer=None, unfused: bool = False, graph: bool = True, kv_f16: bool = False,
                  rope_n_freqs: int | None = None, rope_base: float | None = 500000.0,
-                 layer_range: tuple[int, int] | None = None, dims: dict | None = None, max_batch: int = 0):
+                 layer_range: tuple[int, int] | None = None, dims: dict | None = None, max_batch: int = 0,
+                 share_from: "LlamaModel | None" = None):
         self.mgr = mgr
         d = dims or dims_from_metadata(metadata, tensors)
         self.dims = d
@@ -112,8 +113,12 @@ class LlamaModel:
         call("nfai_hip_llama_create", mgr.handle, C.byref(desc), C.byref(h))
         self.handle = h
         self._keep = []
-        for name, t in tensors.items():
-            self.SetTensor(name, t)
+        if share_from is not None:  # another slot of the same pipeline stage: the donor's weights, no copy, no second repack
+            self._donor = share_from
+            call("nfai_hip_llama_share_tensors", self.handle, share_from.handle)
+        else:
+            for name, t in tensors.items():
+                self.SetTensor(name, t)
         call("nfai_hip_llama_finalize", self.handle)
 
     def SetTensor(self, name: str, t) -> None:

@@ -23,25 +23,48 @@ import numpy as np
 
 
 def partition_layers(n_layers: int, world: int, layer_cost: float = 1.0, head_cost: float = 0.0) -> list[tuple[int, int]]:
-    """Contiguous block ranges balanced by streamed bytes; the last stage also runs lm_head
-    (`head_cost` in units of `layer_cost`), so it gets fewer blocks.  Every stage gets >= 1 block."""
+    """Contiguous block ranges that minimise the largest per-stage cost (streamed bytes); the last stage also runs
+    lm_head (`head_cost` in the units of `layer_cost`), so it gets fewer blocks.  Every stage gets >= 1 block.
+    Among the minimax partitions: the last stage as large as fits, the rest as even as possible (deterministic)."""
     assert 1 <= world <= n_layers
-    total = n_layers * layer_cost + head_cost
-    target = total / world
+
+    def fits(cap: float):
+        """Greedy from the back: the last stage takes as many blocks as fit beside lm_head, then each earlier one."""
+        sizes, left = [], n_layers
+        for r in range(world - 1, -1, -1):
+            extra = head_cost if r == world - 1 else 0.0
+            if r == 0:
+                k = left
+            else:
+                k = min(int((cap - extra) / layer_cost + 1e-9), left - r)  # leave >= 1 block for each earlier stage
+            if k < 1 or k * layer_cost + extra > cap * (1 + 1e-12) + 1e-9:
+                return None
+            sizes.append(k)
+            left -= k
+        return sizes[::-1] if left == 0 else None
+
+    # candidate caps: k blocks, or k blocks + head
+    cands = sorted({k * layer_cost for k in range(1, n_layers + 1)} | {k * layer_cost + head_cost for k in range(1, n_layers + 1)})
+    for cap in cands:
+        sizes = fits(cap)
+        if sizes:
+            break
+    else:  # cannot happen: the largest candidate fits everything
+        raise AssertionError("partition_layers: no feasible partition")
+    # the last stage keeps what the back-greedy pass gave it (the most that fits beside lm_head); the other blocks are
+    # spread as evenly as possible over the earlier stages (sizes differ by at most one, larger ones first)
+    if world > 1:
+        k_last = sizes[-1]
+        rem, n = n_layers - k_last, world - 1
+        sizes = [rem // n + (1 if r < rem % n else 0) for r in range(n)] + [k_last]
     bounds, start = [], 0
-    for r in range(world):
-        if r == world - 1:
-            end = n_layers
-        else:
-            remaining_stages = world - r - 1
-            want = max(1, int(round(target / layer_cost)))
-            end = min(start + want, n_layers - remaining_stages)
-        bounds.append((start, end))
-        start = end
+    for k in sizes:
+        bounds.append((start, start + k))
+        start += k
     return bounds
 
 
-def run_schedule(stage, comm, rank: int, world: int, n_steps: int, first_tokens):
+def schedule_ticks(stage, rank: int, world: int, n_steps: int, first_tokens):
     """`n_steps` tokens for each of `world` in-flight sequences (slots), as a wavefront: at tick t
     stage r runs job j = t - r (slot j % world, step j // world); after the compute of a tick every
     rank posts ONE batch of point-to-point operations (send my result on, receive what I need for the
@@ -51,9 +74,11 @@ def run_schedule(stage, comm, rank: int, world: int, n_steps: int, first_tokens)
     The token of job j (last stage, tick j + world - 1) is the input of job j + world (stage 0, tick
     j + world): it travels in the exchange between those two ticks — the pipeline is exactly full.
 
+    Generator: runs this rank's compute of a tick, then yields (sends=[(buf, dst)], recvs=[(buf, src)]) for
+    the exchange that follows it (empty lists when the rank has nothing to post).
+
     stage API: first(slot, token_host | None) [rank 0; None = use the received token buffer],
-    middle(slot), last(slot); buffers h_in(slot), h_out(slot), tok(slot).
-    comm API: exchange(sends=[(buf, dst)], recvs=[(buf, src)])."""
+    middle(slot), last(slot), last_from_first(slot) [world == 1]; buffers h_in(slot), h_out(slot), tok(slot)."""
     last = world - 1
     n_jobs = n_steps * world
     for tick in range(n_jobs + world - 1):
@@ -81,8 +106,31 @@ def run_schedule(stage, comm, rank: int, world: int, n_steps: int, first_tokens)
                 recvs.append((stage.h_in(slot2), rank - 1))
             elif step2 > 0:
                 recvs.append((stage.tok(slot2), last))
+        yield sends, recvs
+
+
+def run_schedule(stage, comm, rank: int, world: int, n_steps: int, first_tokens):
+    """One rank's side of the schedule (one process per GPU).  comm API: exchange(sends, recvs)."""
+    for sends, recvs in schedule_ticks(stage, rank, world, n_steps, first_tokens):
         if sends or recvs:
             comm.exchange(sends, recvs)
+
+
+def run_schedule_in_process(stages, n_steps: int, first_tokens, copy):
+    """All `world` stages of the pipeline driven by ONE process in lock step (stages that share a device, or a host with
+    several GPUs in one address space): every tick each rank computes, then the posted sends are matched with the posted
+    receives (same tick, same link) and carried out by `copy(dst_buf, src_buf)`."""
+    world = len(stages)
+    gens = [schedule_ticks(st, r, world, n_steps, first_tokens) for r, st in enumerate(stages)]
+    for posted in zip(*gens):
+        for r, (sends, _) in enumerate(posted):
+            for buf, dst in sends:
+                match = [b for b, src in posted[dst][1] if src == r]
+                assert len(match) == 1, f"tick: rank {r} sends to {dst}, which posted {len(match)} receives from it"
+                copy(match[0], buf)
+        n_s = sum(len(s_) for s_, _ in posted)
+        n_r = sum(len(r_) for _, r_ in posted)
+        assert n_s == n_r, "every receive of a tick has its send in the same tick"
 
 
 class TorchComm:
@@ -117,6 +165,49 @@ class TorchComm:
             w.wait()
 
 
+class RcclComm:
+    """The exchange step through the C ABI (nfai_hip_pp_*, nfai_amd/csrc/pp.hip): what a C# NFAI host would call.  The
+    operations of a tick are enqueued on the stage's own stream between nfai_hip_pp_begin / _end (one RCCL group), in order
+    with the stage graphs: no host synchronisation per tick."""
+
+    def __init__(self, mgr, rank: int, world: int, unique_id: bytes):
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib, self.rank, self.world = C, _lib, rank, world
+        uid = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        h = _lib.H()
+        _lib.call("nfai_hip_pp_init", mgr.handle, rank, world, uid, C.byref(h))
+        self.handle = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import _lib
+        uid = (C.c_uint8 * 128)()
+        _lib.call("nfai_hip_pp_unique_id", uid)
+        return bytes(uid)
+
+    def exchange(self, sends, recvs):
+        C, call = self._C, self._lib.call
+        call("nfai_hip_pp_begin", self.handle)
+        for t, dst in sends:
+            if t.numel() == 1:
+                call("nfai_hip_pp_send_token", self.handle, C.c_void_p(t.data_ptr()), dst)
+            else:
+                call("nfai_hip_pp_send_hidden", self.handle, C.c_void_p(t.data_ptr()), t.numel(), dst)
+        for t, src in recvs:
+            if t.numel() == 1:
+                call("nfai_hip_pp_recv_token", self.handle, C.c_void_p(t.data_ptr()), src)
+            else:
+                call("nfai_hip_pp_recv_hidden", self.handle, C.c_void_p(t.data_ptr()), t.numel(), src)
+        call("nfai_hip_pp_end", self.handle)
+
+    def close(self):
+        if self.handle is not None:
+            self._lib.call("nfai_hip_pp_destroy", self.handle)
+            self.handle = None
+
+
 class HipStage:
     """One pipeline stage on one GPU: `world` LlamaModel instances (one per in-flight sequence, each
     with its own KV cache and position) sharing one set of weights resident in HBM."""
@@ -129,8 +220,12 @@ class HipStage:
         tens = {k: (t.data_ptr(), ty, rows, cols) for k, (t, ty, rows, cols) in weights.items()}
         d = dict(E=dims.E, L=dims.L, H=dims.H, Hkv=dims.Hkv, D=dims.D, F=dims.F, V=dims.V, eps=1e-5, rope_dims=dims.D,
                  rope_base=500000.0)
+        # slot 0 owns the tensors (K-quant matrices are repacked into the T16 layout once, there); the other slots alias them
         self.models = [LlamaModel(mgr, {"general.name": dims.name}, tens, capacity, layer_range=layer_range, dims=d,
-                                  kv_f16=kv_f16, graph=graph) for _ in range(n_slots)]
+                                  kv_f16=kv_f16, graph=graph)]
+        for _ in range(1, n_slots):
+            self.models.append(LlamaModel(mgr, {"general.name": dims.name}, tens, capacity, layer_range=layer_range, dims=d,
+                                          kv_f16=kv_f16, graph=graph, share_from=self.models[0]))
         self._hin = [torch.zeros(E, device="cuda", dtype=torch.float32) for _ in range(n_slots)]
         self._hout = [torch.zeros(E, device="cuda", dtype=torch.float32) for _ in range(n_slots)]
         self._tok = [torch.zeros(1, device="cuda", dtype=torch.int32) for _ in range(n_slots)]
@@ -163,6 +258,15 @@ class HipStage:
         m.StageStep(0, self._hin[slot].data_ptr(), None)
         m.TokenToDevice(self._tok[slot].data_ptr())
 
+    def last_from_first(self, slot):
+        """world == 1: the only stage is first and last; `first` already ran the whole network and the argmax is the
+        model's own token word, so the next step picks it up with TOKEN_ON_DEVICE (mirrored into tok(slot) for readers)."""
+        self.models[slot].TokenToDevice(self._tok[slot].data_ptr())
+
+    def dispose(self):
+        for m in reversed(self.models):  # the donor (slot 0) goes last
+            m.Dispose()
+
 
 def run_bench_pipeline(args):
     """bench.py for N > 1: one process per GPU (torch.distributed.run), RCCL point-to-point."""
@@ -181,10 +285,14 @@ def run_bench_pipeline(args):
     if rehearsal:
         local = 0
     torch.cuda.set_device(local)
-    if rehearsal:
+    # Exchange step: the C ABI's own RCCL communicator (nfai_hip_pp_*, what a C# host calls) unless NFAI_PP_COMM=torch
+    # (torch.distributed's NCCL binding) or the one-card rehearsal (gloo through host copies).  Host-side control traffic
+    # (the RCCL unique id, the timing reduction) goes over gloo either way.
+    use_cabi = not rehearsal and os.environ.get("NFAI_PP_COMM", "cabi") != "torch"
+    if rehearsal or use_cabi:
         dist.init_process_group("gloo")
     else:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("cpu:gloo,cuda:nccl", device_id=torch.device("cuda", local))
     dims = synth.BY_NAME[args.model]
     layer_bytes = (2 * dims.H * dims.D * dims.E + 2 * dims.Hkv * dims.D * dims.E + 3 * dims.F * dims.E) * 2
     head_bytes = dims.V * dims.E * 2
@@ -197,7 +305,12 @@ def run_bench_pipeline(args):
     with torch.cuda.stream(stream):
         mgr = HipBufferManager(local, stream=stream.cuda_stream)
         stage = HipStage(torch, mgr, dims, (lb, le), weights, world, C, rank, world, kv_f16=args.kv_f16, graph=not args.no_graph)
-        comm = TorchComm(dist, stage_through_host=rehearsal)
+        if use_cabi:
+            box = [RcclComm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm = RcclComm(mgr, rank, world, box[0])
+        else:
+            comm = TorchComm(dist, stage_through_host=rehearsal)
         toks =[(128000 + 17 * s) % dims.V for s in range(world)]
         # context fill + warmup (also instantiates the RCCL channels and the stage graphs)
         run_schedule(stage, comm, rank, world, args.context + args.warmup, toks)
@@ -213,7 +326,7 @@ def run_bench_pipeline(args):
         stream.synchronize()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
+    t = torch.tensor([dt], device="cpu", dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.barrier()
     dt = float(t.item())
@@ -221,7 +334,7 @@ def run_bench_pipeline(args):
     # bytes this rank streams per step (all its sequences), for the per-GPU achieved bandwidth
     pos_mid = args.context + args.warmup + args.steps // 2
     b_rank = sum(stage.models[0].BytesPerToken(pos_mid)[0] for _ in range(world))
-    gb = torch.tensor([b_rank / 1e9], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
+    gb = torch.tensor([b_rank / 1e9], device="cpu", dtype=torch.float64)
     dist.all_reduce(gb, op=dist.ReduceOp.SUM)
     if rank == 0:
         out = {
@@ -232,11 +345,14 @@ def run_bench_pipeline(args):
             "config": {"workload": f"{dims.name} {'fp16-GGUF' if args.quant == 'f16' else 'Q4_K_M-GGUF'} weights, fp32 activations + {'fp16' if args.kv_f16 else 'fp32'} KV, "
                                    f"{world} independent batch-1 greedy sequences in flight over a {world}-stage layer pipeline, "
                                    f"{args.steps} tokens each after a {args.context}-token context",
-                       "parallelism": f"pp{world}", "layer_ranges": ranges, "kv_capacity": C},
+                       "parallelism": f"pp{world}", "layer_ranges": ranges, "kv_capacity": C,
+                       "exchange": "nfai_hip_pp_* (RCCL send/recv on the stage stream)" if use_cabi else ("gloo via host (one-card rehearsal)" if rehearsal else "torch.distributed nccl")},
             "roofline": {"bound": "hbm", "achieved": float(gb.item()) * args.steps / dt / world, "peak": B.HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": float(gb.item()) * args.steps / dt / world / B.HBM_PEAK_GBPS, "traffic": None,
                          "kernel": "per-GPU average over the whole step (all kernels of the stage)"},
             "cpu_baseline": None,
         }
         print(json.dumps(out))
+    if use_cabi:
+        comm.close()
     dist.destroy_process_group()

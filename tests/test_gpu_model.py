@@ -275,7 +275,9 @@ def test_gguf_file_to_generation_end_to_end(mgr, tmp_path):
         want.append(t)
         lg = ref.step(t)
     assert text == tk.Detokenize(want)
-    assert model.Pos == len(ids) + max(len(want) - 1, 0) + (0 if len(want) == 6 else 1) or True
+    # every prompt token and every generated token that was fed back advanced the position: the 6-token cap stops
+    # before the 6th token is fed; an EOS stops after the (len(want)+1)-th sample without feeding it
+    assert model.Pos == len(ids) + (5 if len(want) == 6 else len(want))
     model.Dispose()
 
 
@@ -304,6 +306,43 @@ def test_prefill_mfma_matches_token_by_token(mgr, dims, n, chunk):
         np.testing.assert_allclose(m.ReadKV(l, False, n - 1), ref.kcache(l)[n - 1], rtol=0, atol=2e-2)
         np.testing.assert_allclose(m.ReadKV(l, True, 3), ref.vcache(l)[3], rtol=0, atol=2e-2)
     # decode continues on the GEMV path from the prefilled cache
+    tok = orc.argmax(want)
+    for _ in range(8):
+        lg, am = m.Step(tok)
+        wl = ref.step(tok)
+        assert np.abs(lg - wl).max() <= tol
+        tok = orc.argmax(wl)
+    m.Dispose()
+
+
+@pytest.mark.parametrize("dims,chunk", [(synth.LLAMA_32_3B, 512), (synth.LLAMA_32_3B, 256), (synth.LLAMA_31_8B, 512), (synth.LLAMA_32_1B, 512)],
+                         ids=["3b-512", "3b-2x256", "8b-512", "1b-512"])
+def test_prefill_full_width_block(mgr, dims, chunk):
+    """BASELINE config 3's prefill leg at its real size: ONE block at the published widths (vocabulary cut to 4096 rows so the
+    oracle stays fast), T = 512 prompt tokens through the MFMA prefill — here gemm_pick takes the 128 x 128 direct-to-LDS
+    kernels with the SiLU*up / fp16 epilogues and the causal tile skipping that carry the headline prefill number — against the
+    oracle's token-by-token fp32 path (LlamaModel.cs:103-126).  chunk = 256: the second chunk runs with pos0 = 256.
+    Stated fp16 tolerance 5e-2 * max(1, max|logit|), same argmax, K/V rows 2e-2, then 8 decode tokens from the prefilled cache."""
+    from dataclasses import replace
+    from nfai_amd.llama_model import LlamaModel
+    d1 = replace(dims, L=1, V=4096, name=dims.name + "-1blk")
+    w = synth.make_weights(d1, seed=33)
+    n, C = 512, 528
+    m = LlamaModel(mgr, synth.make_metadata(d1), w, C, max_batch=chunk)
+    ref = orc.OracleLlama(odesc(d1, C), w)
+    toks = synth.make_tokens(d1, n, seed=14)
+    for t in toks[:-1]:
+        ref.step(int(t), want_logits=False)  # the oracle skips output norm + lm_head when no logits are asked for
+    want = ref.step(int(toks[-1]))
+    got = m.Prefill(toks)
+    assert m.Pos == n
+    tol = 5e-2 * max(1.0, float(np.abs(want).max()))
+    assert np.abs(got - want).max() <= tol, np.abs(got - want).max()
+    assert int(np.argmax(got)) == orc.argmax(want)
+    for pos in (0, 255, 256, n - 1):
+        np.testing.assert_allclose(m.ReadKV(0, False, pos), ref.kcache(0)[pos], rtol=0, atol=2e-2)
+        np.testing.assert_allclose(m.ReadKV(0, True, pos), ref.vcache(0)[pos], rtol=0, atol=2e-2)
+    # the hidden state of the last prompt token (what the output norm + lm_head consumed)
     tok = orc.argmax(want)
     for _ in range(8):
         lg, am = m.Step(tok)

@@ -389,3 +389,102 @@ def test_gemm_f16_variants(mgr, variant, M, N, K, res):
     want = A.astype(np.float64) @ W.astype(np.float64).T + (R.astype(np.float64) if res else 0.0)
     scale = float(np.abs(A.astype(np.float64)).mean() * np.abs(W.astype(np.float64)).mean() * K)
     assert np.abs(got - want).max() <= 2e-6 * np.sqrt(K) * scale + 1e-5, np.abs(got - want).max()
+
+
+def _silu64(x):
+    return x / (1.0 + np.exp(-x))
+
+
+WIDE = [0, 2, 3, 4, 11]     # 128 x 128 tile configurations (what gemm_pick takes for wide N at prefill sizes)
+NARROW = [1, 5, 6, 7, 8]    # 128 x 64
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", WIDE + NARROW)
+@pytest.mark.parametrize("M,N,K", [(512, 1024, 512), (200, 256, 384), (384, 2048, 3072)])
+def test_gemm_f16_fp16_epilogue(mgr, variant, M, N, K):
+    """The fp16 epilogue (P.V writes the Wo GEMM's A operand; the K-quant widening path) in every tile configuration,
+    the 128 x 128 direct-to-LDS ones included: fp64 product rounded once to fp16 => half an fp16 ulp + summation noise."""
+    from nfai_amd._lib import call
+    from nfai_amd.hip import ShaderProperty
+    r = rng(300 + variant + M)
+    A = r.standard_normal((M, K)).astype(np.float16)
+    W = (0.05 * r.standard_normal((N, K))).astype(np.float16)
+    pa, pw = ShaderProperty(mgr, M * K, np.float16), ShaderProperty(mgr, N * K, np.float16)
+    pc = ShaderProperty(mgr, M * N, np.float16)
+    pa.SetValue(A.ravel()); pw.SetValue(W.ravel())
+    call("nfai_hip_gemm_f16_ex", mgr.handle, pa.handle, pw.handle, 0, 0, pc.handle, M, N, K, variant, 1, 1, 1, 0, 0)
+    got = pc.GetValue().reshape(M, N).astype(np.float64)
+    want = A.astype(np.float64) @ W.astype(np.float64).T
+    assert np.abs(got - want).max() <= 1e-3 * np.abs(want).max() + 1e-4, np.abs(got - want).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", WIDE + NARROW)
+@pytest.mark.parametrize("M,F,K", [(512, 1024, 512), (200, 128, 384), (256, 8192, 3072)])
+def test_gemm_f16_silu_up_epilogue(mgr, variant, M, F, K):
+    """gate | up GEMM with act = up * silu(gate) formed in the epilogue (SiLUShader.cs:121-123 + ElementWiseMultiplicationShader.cs:137)
+    at Llama-3.2-3B's gate|up shape (F = 8192, K = 3072: the launch that dominates the 512-token prefill) and small / ragged ones."""
+    from nfai_amd._lib import call
+    from nfai_amd.hip import ShaderProperty
+    r = rng(400 + variant + M)
+    A = r.standard_normal((M, K)).astype(np.float16)
+    Wg = (0.05 * r.standard_normal((F, K))).astype(np.float16)
+    Wu = (0.05 * r.standard_normal((F, K))).astype(np.float16)
+    pa = ShaderProperty(mgr, M * K, np.float16)
+    pg, pu = ShaderProperty(mgr, F * K, np.float16), ShaderProperty(mgr, F * K, np.float16)
+    pc = ShaderProperty(mgr, M * F, np.float16)
+    pa.SetValue(A.ravel()); pg.SetValue(Wg.ravel()); pu.SetValue(Wu.ravel())
+    call("nfai_hip_gemm_f16_ex", mgr.handle, pa.handle, pg.handle, pu.handle, 0, pc.handle, M, 2 * F, K, variant, 2, 1, 1, 0, 0)
+    got = pc.GetValue().reshape(M, F).astype(np.float64)
+    g = A.astype(np.float64) @ Wg.astype(np.float64).T
+    u = A.astype(np.float64) @ Wu.astype(np.float64).T
+    want = u * _silu64(g)
+    assert np.abs(got - want).max() <= 1e-3 * np.abs(want).max() + 1e-4, np.abs(got - want).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 11])
+@pytest.mark.parametrize("pos0", [0, 192])
+def test_gemm_f16_causal_attention_pair(mgr, variant, pos0):
+    """The two head-batched attention GEMMs of the prefill at Llama-3.2-3B's head geometry (H = 24, Hkv = 8, D = 128), T = 512:
+    scores = Q.K^T with the tiles above the causal diagonal skipped (only s <= pos0 + t is ever read by the softmax, so only
+    that part is compared), and att = P.V^T-form product with the K tiles past the last unmasked key skipped (P is zero there,
+    as the causal softmax leaves it), fp16 output.  pos0 > 0 = a later chunk of a chunked prompt."""
+    from nfai_amd._lib import call
+    from nfai_amd.hip import ShaderProperty
+    H, Hkv, D, T = 24, 8, 128, 512
+    G = H // Hkv
+    S = pos0 + T
+    Spad = (S + 63) // 64 * 64
+    r = rng(500 + variant + pos0)
+    Q = r.standard_normal((H, T, D)).astype(np.float16)
+    Kh = r.standard_normal((Hkv, Spad, D)).astype(np.float16)
+    pq, pk = ShaderProperty(mgr, Q.size, np.float16), ShaderProperty(mgr, Kh.size, np.float16)
+    psc = ShaderProperty(mgr, H * T * Spad, np.float32)
+    pq.SetValue(Q.ravel()); pk.SetValue(Kh.ravel())
+    psc.SetValue(np.full(H * T * Spad, 7.0, np.float32))  # skipped tiles must stay untouched
+    call("nfai_hip_gemm_f16_ex", mgr.handle, pq.handle, pk.handle, 0, 0, psc.handle, T, Spad, D, variant, 0, H, G, 1, pos0)
+    sc = psc.GetValue().reshape(H, T, Spad)
+    t_idx, s_idx = np.arange(T)[:, None], np.arange(Spad)[None, :]
+    live = s_idx <= pos0 + t_idx
+    for h in range(H):
+        want = Q[h].astype(np.float64) @ Kh[h // G].astype(np.float64).T
+        d = np.abs(sc[h] - want)[live].max()
+        assert d <= 2e-6 * np.sqrt(D) * D + 1e-4, (h, d)
+    # probabilities: causal softmax of the scores (zeros past the diagonal), then P.V with the masked K tiles skipped
+    P = np.zeros((H, T, Spad), np.float16)
+    for h in range(H):
+        x = np.where(live, sc[h] / np.sqrt(D), -np.inf)
+        e = np.exp(x - x.max(axis=1, keepdims=True))
+        P[h] = (e / e.sum(axis=1, keepdims=True)).astype(np.float16)
+    Vt = r.standard_normal((Hkv, D, Spad)).astype(np.float16)
+    pp, pv = ShaderProperty(mgr, P.size, np.float16), ShaderProperty(mgr, Vt.size, np.float16)
+    po = ShaderProperty(mgr, H * T * D, np.float16)
+    pp.SetValue(P.ravel()); pv.SetValue(Vt.ravel())
+    v2 = variant if D % 128 == 0 or variant in (0, 1, 5, 6, 7, 8) else 1
+    call("nfai_hip_gemm_f16_ex", mgr.handle, pp.handle, pv.handle, 0, 0, po.handle, T, D, Spad, v2, 1, H, G, 2, pos0)
+    att = po.GetValue().reshape(H, T, D).astype(np.float64)
+    for h in range(H):
+        want = P[h].astype(np.float64) @ Vt[h // G].astype(np.float64).T
+        assert np.abs(att[h] - want).max() <= 2e-3 * np.abs(want).max() + 1e-4, (h, np.abs(att[h] - want).max())

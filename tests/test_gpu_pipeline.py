@@ -1,0 +1,149 @@
+"""The multi-GPU path on the one card of the GPU box.
+
+* `HipStage` x 2 (and x 3) driven through `schedule_ticks` by ONE process with device-to-device copies as the exchange
+  (`run_schedule_in_process`): stage graphs, token hand-over on the device, slots that alias one set of weights
+  (`nfai_hip_llama_share_tensors`), fp16 and Q4_K_M-style weights.  Every in-flight sequence must produce exactly the tokens
+  of a single-stage greedy decode (a stage is a contiguous slice of the block loop, LlamaModel.cs:118-121: bit-identical).
+* `RcclComm` (nfai_hip_pp_*: RCCL bound with dlopen, operations on the stage stream) with a one-rank communicator: a grouped
+  send-to-self / receive-from-self of a hidden state and of a token.  Two RCCL ranks cannot share one device, so the
+  multi-rank exchange itself runs only on the driver's multi-GPU node.
+"""
+import numpy as np
+import pytest
+
+import oracle as orc
+from nfai_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+Q4_K, Q6_K = 12, 14
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from nfai_amd.hip import HipBufferManager
+    torch.cuda.set_device(0)
+    stream = torch.cuda.Stream()
+    mgr = HipBufferManager(0, stream=stream.cuda_stream)
+    yield torch, stream, mgr
+    mgr.Dispose()
+
+
+def device_weights(torch, dims, quant):
+    """name -> (device tensor, ggml type, rows, cols) as HipStage takes them, plus the host weights the oracle takes."""
+    w = synth.make_weights(dims, seed=81, std=0.05)
+    dev, host = {}, {}
+    for name, a in w.items():
+        if a.ndim == 1:
+            dev[name] = (torch.from_numpy(a).cuda(), 0, 1, a.shape[0])
+            host[name] = a
+        elif quant:
+            qt = Q6_K if name.endswith(("attn_v.weight", "ffn_down.weight")) or name.startswith(("token_embd", "output.")) else Q4_K
+            f = a.astype(np.float32)
+            raw = orc.quantize_q4k(f) if qt == Q4_K else orc.quantize_q6k(f)
+            deq = (orc.dequant_q4k if qt == Q4_K else orc.dequant_q6k)(raw, a.size).reshape(a.shape)
+            dev[name] = (torch.from_numpy(np.ascontiguousarray(raw)).cuda(), qt, a.shape[0], a.shape[1])
+            host[name] = deq
+        else:
+            dev[name] = (torch.from_numpy(a).cuda(), 1, a.shape[0], a.shape[1])
+            host[name] = a
+    return dev, host
+
+
+def stage_weights(dev, dims, lb, le, first, last):
+    out = {}
+    for name, t in dev.items():
+        if name.startswith("blk."):
+            if lb <= int(name.split(".")[1]) < le:
+                out[name] = t
+        elif name == "token_embd.weight":
+            if first or (last and dims.tied):
+                out[name] = t
+        elif last:
+            out[name] = t
+    return out
+
+
+@pytest.mark.parametrize("quant", [False, True], ids=["f16", "q4_k_m"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_stages_through_schedule_in_process(env, world, quant):
+    torch, stream, mgr = env
+    from nfai_amd.pipeline import HipStage, partition_layers, run_schedule_in_process
+    dims = synth.TINY_D128  # 3 blocks, untied lm_head
+    n_steps, C = 12, 32
+    with torch.cuda.stream(stream):
+        dev, host = device_weights(torch, dims, quant)
+        ranges = partition_layers(dims.L, world)
+        stages = [HipStage(torch, mgr, dims, (lb, le), stage_weights(dev, dims, lb, le, r == 0, r == world - 1), world, C, r, world)
+                  for r, (lb, le) in enumerate(ranges)]
+        first = [(11 + 5 * s) % dims.V for s in range(world)]
+        run_schedule_in_process(stages, n_steps, first, lambda dst, src: dst.copy_(src))
+        stream.synchronize()
+        got = [stages[-1].models[s].FetchTokens(n_steps).tolist() for s in range(world)]
+    for s in range(world):
+        ref = orc.OracleLlama(orc.LlamaDesc(E=dims.E, L=dims.L, H=dims.H, Hkv=dims.Hkv, D=dims.D, F=dims.F, V=dims.V, C=C), host)
+        tok, want = first[s], []
+        for _ in range(n_steps):
+            tok = orc.argmax(ref.step(tok))
+            want.append(tok)
+        assert got[s] == want, (s, got[s], want)
+    # the slots of a stage alias slot 0's weights: one copy of the stage's bytes, whatever the number of sequences in flight
+    for st in stages:
+        b0 = st.models[0].BytesPerToken(0)[0]
+        assert all(m.BytesPerToken(0)[0] == b0 for m in st.models)
+    for st in stages:
+        st.dispose()
+
+
+def test_single_stage_schedule_world1(env):
+    """world == 1 goes through the same schedule (first + last_from_first): tokens == single-model greedy."""
+    torch, stream, mgr = env
+    from nfai_amd.llama_model import LlamaModel
+    from nfai_amd.pipeline import HipStage, run_schedule_in_process
+    dims = synth.TINY
+    with torch.cuda.stream(stream):
+        dev, host = device_weights(torch, dims, False)
+        st = HipStage(torch, mgr, dims, (0, dims.L), dev, 1, 24, 0, 1)
+        run_schedule_in_process([st], 10, [9], lambda dst, src: dst.copy_(src))
+        stream.synchronize()
+        got = st.models[0].FetchTokens(10).tolist()
+        m = LlamaModel(mgr, synth.make_metadata(dims), host, 24)
+        assert got == m.Greedy(9, 10).tolist()
+        m.Dispose()
+        st.dispose()
+
+
+def test_rccl_exchange_one_rank(env):
+    """nfai_hip_pp_* on hardware: communicator of one rank, a group holding a send-to-self and the matching receive for a
+    hidden state (E floats) and for a token word, enqueued on the stage stream."""
+    torch, stream, mgr = env
+    from nfai_amd.pipeline import RcclComm
+    with torch.cuda.stream(stream):
+        comm = RcclComm(mgr, 0, 1, RcclComm.unique_id())
+        a = torch.arange(3072, device="cuda", dtype=torch.float32) * 0.5
+        b = torch.zeros(3072, device="cuda", dtype=torch.float32)
+        ta = torch.tensor([123456], device="cuda", dtype=torch.int32)
+        tb = torch.zeros(1, device="cuda", dtype=torch.int32)
+        stream.synchronize()
+        comm.exchange([(a, 0), (ta, 0)], [(b, 0), (tb, 0)])
+        stream.synchronize()
+        assert torch.equal(a, b) and int(tb.item()) == 123456
+        import ctypes as C
+        from nfai_amd import _lib
+        _lib.call("nfai_hip_pp_bcast_token", comm.handle, C.c_void_p(tb.data_ptr()), 0)
+        stream.synchronize()
+        assert int(tb.item()) == 123456
+        comm.close()
+
+
+def test_pp_bad_arguments(env):
+    import ctypes as C
+    from nfai_amd import _lib
+    torch, stream, mgr = env
+    h = _lib.H()
+    uid = (C.c_uint8 * 128)()
+    with pytest.raises(_lib.NfaiHipError, match="bad arguments"):
+        _lib.call("nfai_hip_pp_init", mgr.handle, 3, 2, uid, C.byref(h))
+    with pytest.raises(_lib.NfaiHipError, match="invalid pipeline handle"):
+        _lib.call("nfai_hip_pp_begin", 12345)

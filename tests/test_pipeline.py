@@ -20,7 +20,11 @@ def test_partition_layers():
         assert all(a[1] == b[0] for a, b in zip(r, r[1:])) and all(e > b for b, e in r)
         cost = [(e - b) * 229.0 + (788.0 if i == world - 1 else 0.0) for i, (b, e) in enumerate(r)]
         assert max(cost) <= 1.35 * (28 * 229.0 + 788.0) / world  # balanced by streamed bytes, lm_head included
-    assert partition_layers(16, 8, 1.0, 3.4) == [(0, 2), (2, 4), (4, 6), (6, 8), (8, 10), (10, 12), (12, 14), (14, 16)] or True
+    # lm_head worth 3.4 blocks: the last stage keeps one block, the other 15 are spread evenly (the largest stage, 1 + 3.4,
+    # cannot be undercut: every stage owns at least one block)
+    assert partition_layers(16, 8, 1.0, 3.4) == [(0, 3), (3, 5), (5, 7), (7, 9), (9, 11), (11, 13), (13, 15), (15, 16)]
+    assert partition_layers(16, 8, 1.0, 0.0) == [(b, b + 2) for b in range(0, 16, 2)]
+    assert partition_layers(32, 8, 218.0, 1050.0) == [(0, 5), (5, 10), (10, 15), (15, 19), (19, 23), (23, 27), (27, 31), (31, 32)]
     assert partition_layers(3, 3) == [(0, 1), (1, 2), (2, 3)]
 
 
