@@ -184,7 +184,11 @@ enum nfai_llama_flags {
     NFAI_LLAMA_UNFUSED = 1u << 0,   /* run the 16-op chain 1:1 with the reference (parity mode) */
     NFAI_LLAMA_NO_GRAPH = 1u << 1,  /* fused kernels, eager launches (no hipGraph) */
     NFAI_LLAMA_KV_F16 = 1u << 2,    /* fp16 KV cache (default fp32 = the reference's) */
-    NFAI_LLAMA_PREFETCH = 1u << 3   /* side-stream prefetch of the next GEMV's first weight bytes (perf hint only) */
+    NFAI_LLAMA_PREFETCH = 1u << 3,  /* side-stream prefetch of the next GEMV's first weight bytes (perf hint only) */
+    NFAI_LLAMA_ENGINE = 1u << 4     /* fp16 models: Wo -> gate|up -> Wdown -> next q|k|v of a block as ONE launch of the
+                                       weight-streaming engine (kernels_engine.hip) instead of four; same results up to the
+                                       summation order.  Ignored (five-launch path) when a tensor is not fp16 or a width is
+                                       not a multiple of 512.  The environment variable NFAI_ENGINE=0/1 overrides the flag. */
 };
 
 typedef struct nfai_llama_desc {

@@ -9,7 +9,7 @@ SO_PATH = os.environ.get("NFAI_HIP_LIB") or os.path.join(_HERE, "csrc", "libnfai
 
 OK, ERR_INVALID, ERR_HIP, ERR_OOM, ERR_KV_FULL, ERR_UNSUPPORTED, ERR_STATE = range(7)
 F32, F16, Q4_K, Q6_K = 0, 1, 12, 14
-LLAMA_UNFUSED, LLAMA_NO_GRAPH, LLAMA_KV_F16, LLAMA_PREFETCH = 1, 2, 4, 8
+LLAMA_UNFUSED, LLAMA_NO_GRAPH, LLAMA_KV_F16, LLAMA_PREFETCH, LLAMA_ENGINE = 1, 2, 4, 8, 16
 TOKEN_ON_DEVICE = 0xFFFFFFFF
 
 

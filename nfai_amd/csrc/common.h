@@ -173,6 +173,30 @@ constexpr uint32_t ATTN_NSPLIT_MAX = 32;
 size_t attn_partials_bytes(uint32_t H, uint32_t Hkv, uint32_t D);
 hipError_t launch_attn_decode(const AttnArgs &a, hipStream_t s);
 
+// the weight-streaming engine (kernels_engine.hip): Wo + residual -> gate|up -> Wdown + residual -> next block's q|k|v, one launch
+struct EngineArgs {
+    uint32_t n_ops = 3;              // 3: ends with Wdown (last block of the range); 4: + the next block's q|k|v
+    uint32_t E = 0, F = 0, HD = 0;
+    const void *Wo = nullptr, *Wgate = nullptr, *Wup = nullptr, *Wdown = nullptr;   // fp16 [N][K]
+    const void *Wqkv[3] = {nullptr, nullptr, nullptr};
+    uint32_t qkv_rows[3] = {0, 0, 0};
+    const float *att = nullptr, *x_in = nullptr, *gamma_ffn = nullptr, *gamma_next = nullptr;
+    float eps = 0.f;
+    uint64_t *g_h = nullptr, *g_act = nullptr, *g_x = nullptr;   // granule vectors (E, F, E), zero-initialised once
+    const uint32_t *epoch = nullptr;                             // device word, advanced once per token
+    float *x_out = nullptr;          // plain [E]: the block's output
+    float *q_out = nullptr;
+    void *kcache = nullptr, *vcache = nullptr;                   // the NEXT block's caches
+    int kv_type = NFAI_F32;
+    uint64_t kv_pos_stride = 0, kv_head_stride = 0;
+    const float *rope_cs = nullptr;
+    uint32_t rope_dims = 0, D = 0;
+    const uint32_t *pos_dev = nullptr;
+    uint32_t *err = nullptr;         // device word: non-zero after a bounded wait gave up
+    uint32_t n_cu = 256;
+};
+hipError_t launch_engine(const EngineArgs &a, hipStream_t s);
+
 // basic 1:1 ops
 hipError_t launch_embed(const void *table, int type, const uint32_t *tok, float *y, uint32_t E, hipStream_t s);
 hipError_t launch_rmsnorm(const float *x, const float *g, float *y, uint32_t E, float eps, hipStream_t s);
@@ -195,7 +219,7 @@ hipError_t launch_argmax(const float *x, uint32_t n, uint32_t *out_idx, void *pa
 // per-token prologue: embed row -> x, cos/sin table for the current position
 hipError_t launch_token_begin(const void *table, int type, const uint32_t *tok, float *x, uint32_t E,
                               const float *freqs, float *rope_cs, uint32_t n_freq, const uint32_t *pos_dev,
-                              hipStream_t s);
+                              hipStream_t s, uint32_t *epoch = nullptr);  // epoch: the engine's per-token tag, advanced here
 hipError_t launch_pos_advance(uint32_t *pos_dev, hipStream_t s);
 
 }  // namespace nfai

@@ -287,9 +287,10 @@ hipError_t launch_argmax(const float *x, uint32_t n, uint32_t *out_idx, void *pa
 // (RoPEShader.cs:254-256 recomputes cos/sin per element per layer).
 // ---------------------------------------------------------------------------------------------
 __global__ void k_token_begin(const void *table, int type, const uint32_t *tok, float *x, uint32_t E,
-                              const float *freqs, float *rope_cs, uint32_t n_freq, const uint32_t *pos_dev)
+                              const float *freqs, float *rope_cs, uint32_t n_freq, const uint32_t *pos_dev, uint32_t *epoch)
 {
     const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (epoch != nullptr && d == 0) epoch[0] = epoch[0] + 1;  // tag of this token's hand-offs inside the engine launches
     if (table != nullptr && d < E) {
         const uint64_t row = (uint64_t)tok[0] * E;
         if (type == NFAI_F16) x[d] = (float)reinterpret_cast<const _Float16 *>(table)[row + d];
@@ -304,10 +305,10 @@ __global__ void k_token_begin(const void *table, int type, const uint32_t *tok, 
 
 hipError_t launch_token_begin(const void *table, int type, const uint32_t *tok, float *x, uint32_t E,
                               const float *freqs, float *rope_cs, uint32_t n_freq, const uint32_t *pos_dev,
-                              hipStream_t s)
+                              hipStream_t s, uint32_t *epoch)
 {
     const uint32_t n = E > n_freq ? E : n_freq;
-    k_token_begin<<<(n + 255) / 256, 256, 0, s>>>(table, type, tok, x, E, freqs, rope_cs, n_freq, pos_dev);
+    k_token_begin<<<(n + 255) / 256, 256, 0, s>>>(table, type, tok, x, E, freqs, rope_cs, n_freq, pos_dev, epoch);
     return hipGetLastError();
 }
 

@@ -37,7 +37,7 @@ struct Layer {
     void *kcache = nullptr, *vcache = nullptr;
 };
 
-enum KClass { KC_QKV = 0, KC_ATTN = 1, KC_WO = 2, KC_GATEUP = 3, KC_DOWN = 4, KC_LMHEAD = 5, KC_OTHER = 6, KC_N = 8 };
+enum KClass { KC_QKV = 0, KC_ATTN = 1, KC_WO = 2, KC_GATEUP = 3, KC_DOWN = 4, KC_LMHEAD = 5, KC_OTHER = 6, KC_ENGINE = 7, KC_N = 8 };
 
 constexpr uint32_t RING_LEN = 8192;
 
@@ -48,6 +48,9 @@ struct Model {
     bool finalized = false;
     bool first_stage = false, last_stage = false;
     bool unfused = false, use_graph = true, kv_f16 = false;
+    bool engine = false;             // requested: one engine launch per block where the tensors allow it
+    uint64_t *d_gran = nullptr;      // engine hand-off granules: per block h (E) | act (F) | x (E)
+    uint32_t *d_epoch = nullptr, *d_engerr = nullptr;
     Tensor token_embd, output_norm, output;
     std::vector<Layer> layers;  // index = block - layer_begin
     uint64_t kv_pos_stride = 0, kv_head_stride = 0;
@@ -72,6 +75,7 @@ struct Model {
         uint64_t wf16_bytes = 0;
     } pf;
     uint32_t pos_host = 0;
+    const float *x_last = nullptr;   // where the last enqueued token left the hidden state (m->x, or m->h on the engine path)
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     bool prefetch = false, s2_used = false;  // side-stream weight prefetch (NFAI_LLAMA_PREFETCH)
@@ -299,51 +303,62 @@ GemvArgs gemv_base(Model *m, const Tensor &w, const float *x, uint32_t K)
     return a;
 }
 
+// [RMSNorm + Wq, Wk, Wv + RoPE + KV write] of block L on the activation vector x (TransformerBlock.cs:129-141).
+int submit_qkv(Model *m, Layer &L, const float *x, Sched &sch)
+{
+    const nfai_llama_desc &d = m->d;
+    // One launch when q, k, v share an encoding; Q4_K_M files keep attn_v in Q6_K on some blocks:
+    // then the segments that differ get their own launch (same kernel family, same epilogue).
+    const Tensor *seg[3] = {&L.wq, &L.wk, &L.wv};
+    auto t16 = [](int ty) { return ty == NFAI_Q4_K_T16 || ty == NFAI_Q6_K_T16; };
+    for (int first = 0; first < 3;) {
+        int last = first;
+        // segments of one encoding share a launch; so do T16 Q4_K and Q6_K segments (mixed kernel, kernels_gemv_kqm.hip)
+        while (last + 1 < 3 && (seg[last + 1]->type == seg[first]->type || (t16(seg[last + 1]->type) && t16(seg[first]->type)))) last++;
+        GemvArgs a = gemv_base(m, *seg[first], x, d.E);
+        for (int i = first; i <= last; i++) {
+            if (seg[i]->type != seg[first]->type) a.w_type = NFAI_KQ_MIXED;
+            if (seg[i]->type == NFAI_Q6_K_T16) a.seg6_mask |= 1u << i;
+        }
+        for (int i = 0; i < 3; i++) {
+            const bool in = i >= first && i <= last;
+            a.W[i] = in ? seg[i]->ptr : seg[first]->ptr;
+            a.seg_rows[i] = in ? (uint32_t)seg[i]->rows : 0;
+        }
+        a.gamma = static_cast<const float *>(L.attn_norm.ptr);
+        a.mode = GEMV_QKV_ROPE;
+        a.y = m->q;
+        a.kcache = L.kcache; a.vcache = L.vcache;
+        a.kv_type = m->kv_f16 ? NFAI_F16 : NFAI_F32;
+        a.kv_pos_stride = m->kv_pos_stride; a.kv_head_stride = m->kv_head_stride;
+        a.rope_cs = m->d_ropecs; a.rope_dims = d.rope_dims;
+        a.H = d.H; a.Hkv = d.Hkv; a.D = d.D;
+        S_TRY(sch.submit(op_gemv(KC_QKV, a)));
+        first = last + 1;
+    }
+    return NFAI_OK;
+}
+
+// scores + softmax + weighted V of block L in one launch (TransformerBlock.cs:144-148)
+int submit_attn(Model *m, Layer &L, Sched &sch)
+{
+    const nfai_llama_desc &d = m->d;
+    AttnArgs a;
+    a.q = m->q; a.kcache = L.kcache; a.vcache = L.vcache;
+    a.kv_type = m->kv_f16 ? NFAI_F16 : NFAI_F32;
+    a.kv_pos_stride = m->kv_pos_stride; a.kv_head_stride = m->kv_head_stride;
+    a.o = m->att; a.H = d.H; a.Hkv = d.Hkv; a.D = d.D; a.C = d.C;
+    a.pos_dev = m->d_pos; a.partials = m->d_attn_part;
+    a.n_cu = (uint32_t)m->ctx->prop.multiProcessorCount;
+    return sch.submit(op_attn(KC_ATTN, a));
+}
+
 // One block, fused path (TransformerBlock.cs:127-184 in five launches + the attention merge).
 int block_fused(Model *m, Layer &L, Sched &sch)
 {
     const nfai_llama_desc &d = m->d;
-    {
-        // One launch when q, k, v share an encoding; Q4_K_M files keep attn_v in Q6_K on some blocks:
-        // then the segments that differ get their own launch (same kernel family, same epilogue).
-        const Tensor *seg[3] = {&L.wq, &L.wk, &L.wv};
-        auto t16 = [](int ty) { return ty == NFAI_Q4_K_T16 || ty == NFAI_Q6_K_T16; };
-        for (int first = 0; first < 3;) {
-            int last = first;
-            // segments of one encoding share a launch; so do T16 Q4_K and Q6_K segments (mixed kernel, kernels_gemv_kqm.hip)
-            while (last + 1 < 3 && (seg[last + 1]->type == seg[first]->type || (t16(seg[last + 1]->type) && t16(seg[first]->type)))) last++;
-            GemvArgs a = gemv_base(m, *seg[first], m->x, d.E);
-            for (int i = first; i <= last; i++) {
-                if (seg[i]->type != seg[first]->type) a.w_type = NFAI_KQ_MIXED;
-                if (seg[i]->type == NFAI_Q6_K_T16) a.seg6_mask |= 1u << i;
-            }
-            for (int i = 0; i < 3; i++) {
-                const bool in = i >= first && i <= last;
-                a.W[i] = in ? seg[i]->ptr : seg[first]->ptr;
-                a.seg_rows[i] = in ? (uint32_t)seg[i]->rows : 0;
-            }
-            a.gamma = static_cast<const float *>(L.attn_norm.ptr);
-            a.mode = GEMV_QKV_ROPE;
-            a.y = m->q;
-            a.kcache = L.kcache; a.vcache = L.vcache;
-            a.kv_type = m->kv_f16 ? NFAI_F16 : NFAI_F32;
-            a.kv_pos_stride = m->kv_pos_stride; a.kv_head_stride = m->kv_head_stride;
-            a.rope_cs = m->d_ropecs; a.rope_dims = d.rope_dims;
-            a.H = d.H; a.Hkv = d.Hkv; a.D = d.D;
-            S_TRY(sch.submit(op_gemv(KC_QKV, a)));
-            first = last + 1;
-        }
-    }
-    {
-        AttnArgs a;
-        a.q = m->q; a.kcache = L.kcache; a.vcache = L.vcache;
-        a.kv_type = m->kv_f16 ? NFAI_F16 : NFAI_F32;
-        a.kv_pos_stride = m->kv_pos_stride; a.kv_head_stride = m->kv_head_stride;
-        a.o = m->att; a.H = d.H; a.Hkv = d.Hkv; a.D = d.D; a.C = d.C;
-        a.pos_dev = m->d_pos; a.partials = m->d_attn_part;
-        a.n_cu = (uint32_t)m->ctx->prop.multiProcessorCount;
-        S_TRY(sch.submit(op_attn(KC_ATTN, a)));
-    }
+    S_TRY(submit_qkv(m, L, m->x, sch));
+    S_TRY(submit_attn(m, L, sch));
     {
         GemvArgs a = gemv_base(m, L.wo, m->att, d.H * d.D);
         a.mode = GEMV_RESIDUAL; a.res = m->x; a.y = m->h;
@@ -362,6 +377,21 @@ int block_fused(Model *m, Layer &L, Sched &sch)
         S_TRY(sch.submit(op_gemv(KC_DOWN, a)));
     }
     return NFAI_OK;
+}
+
+// The engine path (kernels_engine.hip) needs every matrix of every block in fp16 and every K a multiple of 512 (one LDS-DMA
+// piece = 512 weights of one row), every gathered vector a multiple of 128 granules, and one workgroup per CU.
+bool engine_ok(const Model *m)
+{
+    if (!m->engine || m->unfused || !m->d_gran) return false;
+    const nfai_llama_desc &d = m->d;
+    const uint32_t HD = d.H * d.D;
+    if (d.E % 512 || d.F % 512 || HD % 512 || (d.Hkv * d.D) % 2) return false;
+    if ((2 * (size_t)d.E + std::max(HD, d.F)) * 4 + 2048 + 5 * 8 * 1024 > 160 * 1024) return false;  // LDS: vectors + a 5-slot ring
+    for (const Layer &L : m->layers)
+        for (const Tensor *t : {&L.wq, &L.wk, &L.wv, &L.wo, &L.wgate, &L.wup, &L.wdown})
+            if (t->type != NFAI_F16) return false;
+    return true;
 }
 
 // One block as the reference's 16-dispatch chain, op for op (parity mode; needs the host copy
@@ -406,7 +436,7 @@ int enqueue_token(Model *m, bool with_head)
     if (m->first_stage && emb_kq)
         K_TRY(KC_OTHER, launch_embed_kq(m->token_embd.ptr, m->token_embd.type, m->token_embd.rows, m->d_tok, m->x, d.E, s));
     K_TRY(KC_OTHER, launch_token_begin(m->first_stage && !emb_kq ? m->token_embd.ptr : nullptr, m->token_embd.type, m->d_tok, m->x, d.E,
-                                       m->d_freqs, m->d_ropecs, nfreq, m->d_pos, s));
+                                       m->d_freqs, m->d_ropecs, nfreq, m->d_pos, s, m->d_epoch));
     if (m->unfused) {
         for (Layer &L : m->layers) {
             int rc = block_unfused(m, L, rec);
@@ -425,13 +455,50 @@ int enqueue_token(Model *m, bool with_head)
         return NFAI_OK;
     }
     Sched sch{m, rec};
-    for (Layer &L : m->layers) {
-        int rc = block_fused(m, L, sch);
-        if (rc) return rc;
+    const float *x_final = m->x;
+    if (engine_ok(m)) {
+        // [q|k|v of the first block] then per block [attention] [engine: Wo -> gate|up -> Wdown -> next block's q|k|v].
+        // The block input / output alternate between m->x and m->h so that no CU overwrites a vector another CU still reads.
+        S_TRY(submit_qkv(m, m->layers[0], m->x, sch));
+        for (size_t i = 0; i < m->layers.size(); i++) {
+            Layer &L = m->layers[i];
+            float *xin = (i & 1) ? m->h : m->x, *xout = (i & 1) ? m->x : m->h;
+            S_TRY(submit_attn(m, L, sch));
+            EngineArgs e;
+            const bool more = i + 1 < m->layers.size();
+            e.n_ops = more ? 4 : 3;
+            e.E = d.E; e.F = d.F; e.HD = d.H * d.D;
+            e.Wo = L.wo.ptr; e.Wgate = L.wgate.ptr; e.Wup = L.wup.ptr; e.Wdown = L.wdown.ptr;
+            e.att = m->att; e.x_in = xin; e.x_out = xout;
+            e.gamma_ffn = static_cast<const float *>(L.ffn_norm.ptr);
+            e.eps = d.eps;
+            uint64_t *gl = m->d_gran + i * (2 * (size_t)d.E + d.F);
+            e.g_h = gl; e.g_act = gl + d.E; e.g_x = gl + d.E + d.F;
+            e.epoch = m->d_epoch; e.err = m->d_engerr;
+            e.n_cu = (uint32_t)m->ctx->prop.multiProcessorCount;
+            if (more) {
+                Layer &N = m->layers[i + 1];
+                e.gamma_next = static_cast<const float *>(N.attn_norm.ptr);
+                e.Wqkv[0] = N.wq.ptr; e.Wqkv[1] = N.wk.ptr; e.Wqkv[2] = N.wv.ptr;
+                e.qkv_rows[0] = (uint32_t)N.wq.rows; e.qkv_rows[1] = (uint32_t)N.wk.rows; e.qkv_rows[2] = (uint32_t)N.wv.rows;
+                e.q_out = m->q; e.kcache = N.kcache; e.vcache = N.vcache;
+                e.kv_type = m->kv_f16 ? NFAI_F16 : NFAI_F32;
+                e.kv_pos_stride = m->kv_pos_stride; e.kv_head_stride = m->kv_head_stride;
+                e.rope_cs = m->d_ropecs; e.rope_dims = d.rope_dims; e.D = d.D; e.pos_dev = m->d_pos;
+            }
+            S_TRY(sch.submit(op_fn(KC_ENGINE, [e](hipStream_t st) { return launch_engine(e, st); })));
+            x_final = xout;
+        }
+    } else {
+        for (Layer &L : m->layers) {
+            int rc = block_fused(m, L, sch);
+            if (rc) return rc;
+        }
     }
+    m->x_last = x_final;
     if (m->last_stage && with_head) {
         const Tensor &head = m->output.ptr ? m->output : m->token_embd;
-        GemvArgs a = gemv_base(m, head, m->x, d.E);
+        GemvArgs a = gemv_base(m, head, x_final, d.E);
         a.gamma = static_cast<const float *>(m->output_norm.ptr);
         a.y = m->logits;
         S_TRY(sch.submit(op_gemv(KC_LMHEAD, a)));
@@ -491,6 +558,15 @@ int set_token_async(Model *m, uint32_t tok)
 
 uint64_t tensor_bytes(const Tensor &t) { return t.ptr ? weight_row_bytes(t.type, t.cols) * t.rows : 0; }
 
+// A bounded wait inside an engine launch gave up (a workgroup was not resident, or a producer never published): the
+// results of that token are not valid.  The word is sticky until the model is reset.
+int engine_failed(Model *m, uint32_t code)
+{
+    return fail(NFAI_ERR_HIP, "engine launch gave up waiting (code 0x%x: 0x10 ring slot, 0x20 activation, 0x40 weights, 0x80 gather, "
+                              "0x100-0x400 consumers): are all %d workgroups resident?  NFAI_ENGINE=0 selects the five-launch path",
+                code, m->ctx->prop.multiProcessorCount);
+}
+
 }  // namespace
 
 // ---- C ABI -----------------------------------------------------------------------------------
@@ -523,6 +599,10 @@ NFAI_API int32_t nfai_hip_llama_create(nfai_ctx_t ch, const nfai_llama_desc *des
         m->prefetch = env ? (env[0] == '1') : ((d.flags & NFAI_LLAMA_PREFETCH) != 0);
         if (m->prefetch) HIP_TRY(hipStreamCreateWithFlags(&m->s2, hipStreamNonBlocking));
     }
+    {
+        const char *env = getenv("NFAI_ENGINE");
+        m->engine = !m->unfused && (env ? (env[0] == '1') : ((d.flags & NFAI_LLAMA_ENGINE) != 0));
+    }
     if (m->unfused && m->kv_f16) { delete m; return fail(NFAI_ERR_INVALID, "llama_create: the 1:1 chain keeps the reference's fp32 KV cache"); }
     m->layers.resize(d.layer_end - d.layer_begin);
     m->kv_esz = m->kv_f16 ? 2 : 4;
@@ -544,6 +624,9 @@ NFAI_API int32_t nfai_hip_llama_create(nfai_ctx_t ch, const nfai_llama_desc *des
     DALLOC(m->d_freqs, (d.D / 2 + 8) * 4);
     DALLOC(m->d_ropecs, (d.D + 16) * 4);
     DALLOC(m->d_argmax_part, 4096);
+    DALLOC(m->d_epoch, 256);
+    DALLOC(m->d_engerr, 256);
+    if (m->engine) DALLOC(m->d_gran, (size_t)m->layers.size() * (2 * (size_t)d.E + d.F) * 8);
     DALLOC(m->d_attn_part, attn_partials_bytes(d.H, d.Hkv, d.D));
     DALLOC(m->x, d.E * 4);
     DALLOC(m->h, d.E * 4);
@@ -613,7 +696,7 @@ NFAI_API int32_t nfai_hip_llama_destroy(nfai_model_t h)
         free_t(L.ffn_norm); free_t(L.wgate); free_t(L.wup); free_t(L.wdown);
         hipFree(L.kcache); hipFree(L.vcache);
     }
-    void *ptrs[] = {m->d_pos, m->d_tok, m->d_ring, m->d_freqs, m->d_ropecs, m->d_argmax_part, m->d_attn_part, m->x, m->h,
+    void *ptrs[] = {m->d_gran, m->d_epoch, m->d_engerr, m->d_pos, m->d_tok, m->d_ring, m->d_freqs, m->d_ropecs, m->d_argmax_part, m->d_attn_part, m->x, m->h,
                     m->q, m->att, m->act, m->logits, m->xn, m->qraw, m->scores, m->wts, m->proj, m->gate, m->up};
     for (void *p : ptrs) if (p) hipFree(p);
     void *pfp[] = {m->pf.toks, m->pf.X, m->pf.H1, m->pf.Q, m->pf.K, m->pf.V, m->pf.ATT, m->pf.G, m->pf.U, m->pf.SC,
@@ -781,7 +864,9 @@ NFAI_API int32_t nfai_hip_llama_decode_step(nfai_model_t h, uint32_t token, floa
     hipStream_t s = m->ctx->stream;
     if (logits_host) HIP_TRY(hipMemcpyAsync(logits_host, m->logits, (size_t)m->d.V * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(m->h_pin, m->d_tok, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(m->h_pin + 1, m->d_engerr, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (m->h_pin[1]) return engine_failed(m, m->h_pin[1]);
     if (argmax) *argmax = m->h_pin[0];
     return NFAI_OK;
 }
@@ -814,7 +899,9 @@ NFAI_API int32_t nfai_hip_llama_fetch_tokens(nfai_model_t h, uint32_t n, uint32_
     hipStream_t s = m->ctx->stream;
     std::vector<uint32_t> ring(RING_LEN);
     HIP_TRY(hipMemcpyAsync(ring.data(), m->d_ring, RING_LEN * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(m->h_pin + 1, m->d_engerr, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (m->h_pin[1]) return engine_failed(m, m->h_pin[1]);
     for (uint32_t i = 0; i < n; i++) tokens_out[i] = ring[(m->pos_host - n + i) % RING_LEN];
     return NFAI_OK;
 }
@@ -949,6 +1036,7 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
     const uint32_t newpos = pos0 + T;
     HIP_TRY(hipMemcpyAsync(m->d_pos, &newpos, 4, hipMemcpyHostToDevice, s));
     m->pos_host = newpos;
+    m->x_last = m->x;
     return NFAI_OK;
 }
 
@@ -1026,7 +1114,7 @@ static int stage_enqueue(Model *m, const void *hidden_in, void *hidden_out)
     if (!m->first_stage) HIP_TRY(hipMemcpyAsync(m->x, hidden_in, (size_t)m->d.E * 4, hipMemcpyDeviceToDevice, s));
     int rc = enqueue_token(m, true);
     if (rc) return rc;
-    if (!m->last_stage) HIP_TRY(hipMemcpyAsync(hidden_out, m->x, (size_t)m->d.E * 4, hipMemcpyDeviceToDevice, s));
+    if (!m->last_stage) HIP_TRY(hipMemcpyAsync(hidden_out, m->x_last ? m->x_last : m->x, (size_t)m->d.E * 4, hipMemcpyDeviceToDevice, s));
     return NFAI_OK;
 }
 
@@ -1102,6 +1190,7 @@ NFAI_API int32_t nfai_hip_llama_set_pos(nfai_model_t h, uint32_t pos)
     MODEL_OR_FAIL(m, h);
     if (pos > m->d.C) return fail(NFAI_ERR_INVALID, "set_pos: %u > capacity %u", pos, m->d.C);
     HIP_TRY(hipMemcpyAsync(m->d_pos, &pos, 4, hipMemcpyHostToDevice, m->ctx->stream));
+    HIP_TRY(hipMemsetAsync(m->d_engerr, 0, 4, m->ctx->stream));
     HIP_TRY(hipStreamSynchronize(m->ctx->stream));
     m->pos_host = pos;
     return NFAI_OK;
@@ -1123,7 +1212,7 @@ NFAI_API int32_t nfai_hip_llama_read(nfai_model_t h, int32_t which, float *host,
     const float *src = nullptr;
     uint64_t cap = 0;
     switch (which) {
-        case 0: src = m->x; cap = d.E; break;
+        case 0: src = m->x_last ? m->x_last : m->x; cap = d.E; break;
         case 1: src = m->q; cap = (uint64_t)d.H * d.D; break;
         case 2: src = m->att; cap = (uint64_t)d.H * d.D; break;
         case 3: src = m->act; cap = d.F; break;

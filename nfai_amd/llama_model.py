@@ -91,7 +91,7 @@ class LlamaModel:
                  tokenizer=None, unfused: bool = False, graph: bool = True, kv_f16: bool = False,
                  rope_n_freqs: int | None = None, rope_base: float | None = 500000.0,
                  layer_range: tuple[int, int] | None = None, dims: dict | None = None, max_batch: int = 0,
-                 share_from: "LlamaModel | None" = None):
+                 share_from: "LlamaModel | None" = None, engine: bool | None = None):
         self.mgr = mgr
         d = dims or dims_from_metadata(metadata, tensors)
         self.dims = d
@@ -103,6 +103,8 @@ class LlamaModel:
         self.firstInput = True
         lb, le = layer_range or (0, d["L"])
         flags = (_lib.LLAMA_UNFUSED if unfused else 0) | (0 if graph else _lib.LLAMA_NO_GRAPH) | (_lib.LLAMA_KV_F16 if kv_f16 else 0)
+        if engine:  # the one-launch-per-block weight-streaming engine (fp16 models); None = the library's default
+            flags |= _lib.LLAMA_ENGINE
         rd = d["rope_dims"]
         desc = _lib.LlamaDescC(d["E"], d["L"], d["H"], d["Hkv"], d["D"], d["F"], d["V"], int(contextSize), d["eps"],
                                # the reference ignores llama.rope.freq_base and uses 500000 (TransformerBlock.cs:33)
@@ -210,12 +212,12 @@ class LlamaModel:
         ms = (C.c_float * 8)()
         n = (C.c_uint32 * 8)()
         call("nfai_hip_llama_profile_step", self.handle, int(token), ms, n)
-        names = ["qkv", "attn", "wo", "gateup", "down", "lmhead", "other"]
+        names = ["qkv", "attn", "wo", "gateup", "down", "lmhead", "other", "engine"]
         return {k: (ms[i], n[i]) for i, k in enumerate(names)}
 
     def ProfileKernel(self, token: int, kernel_class: str, reps: int = 4) -> float:
         """Average duration in microseconds of one kernel class: its launches of a step replayed back to back, `reps` rounds."""
-        names = ["qkv", "attn", "wo", "gateup", "down", "lmhead", "other"]
+        names = ["qkv", "attn", "wo", "gateup", "down", "lmhead", "other", "engine"]
         us = C.c_float()
         call("nfai_hip_llama_profile_kernel", self.handle, int(token), names.index(kernel_class), int(reps), C.byref(us))
         return us.value

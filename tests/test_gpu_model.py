@@ -350,3 +350,91 @@ def test_prefill_full_width_block(mgr, dims, chunk):
         assert np.abs(lg - wl).max() <= tol
         tok = orc.argmax(wl)
     m.Dispose()
+
+
+# ---- the weight-streaming engine: one launch per block (kernels_engine.hip) ---------------------------------------------
+@pytest.mark.parametrize("mode", ["graph", "eager"])
+def test_engine_decode_matches_oracle(mgr, mode):
+    """Wo -> gate|up -> Wdown -> next block's q|k|v in one launch per block (LDS-DMA weight ring, granule hand-offs) against the
+    oracle, token by token, with the intermediate state; then against the five-launch path of the same library (same kernels'
+    arithmetic, another summation tree): the stated end-to-end tolerance, identical greedy tokens."""
+    from nfai_amd.llama_model import LlamaModel
+    dims = synth.TINY_D128  # E = HD = 512, F = 1024: every K is a multiple of 512
+    w = synth.make_weights(dims, seed=91, std=0.05)
+    C = 48
+    m = LlamaModel(mgr, synth.make_metadata(dims), w, C, graph=mode == "graph", engine=True)
+    five = LlamaModel(mgr, synth.make_metadata(dims), w, C, engine=False)
+    ref = orc.OracleLlama(odesc(dims, C), w)
+    for i, t in enumerate(synth.make_tokens(dims, 40, seed=5)):
+        lg, am = m.Step(int(t))
+        lf, _ = five.Step(int(t))
+        want = ref.step(int(t))
+        assert np.abs(lg - want).max() <= logit_tol(want), (i, np.abs(lg - want).max())
+        assert np.abs(lg - lf).max() <= logit_tol(want)
+        assert am == orc.argmax(want)
+    np.testing.assert_allclose(m.Read(0, dims.E), ref.hidden(), rtol=0, atol=1e-3)
+    for l in range(dims.L):
+        np.testing.assert_allclose(m.ReadKV(l, False, 39), ref.kcache(l)[39], rtol=0, atol=1e-3)
+        np.testing.assert_allclose(m.ReadKV(l, True, 17), ref.vcache(l)[17], rtol=0, atol=1e-3)
+    # greedy on the device, reset, bit-reproducibility
+    m.Reset()
+    ref2 = orc.OracleLlama(odesc(dims, C), w)
+    want, tok = [], 5
+    for _ in range(24):
+        tok = orc.argmax(ref2.step(tok))
+        want.append(tok)
+    assert m.Greedy(5, 24).tolist() == want
+    m.Reset()
+    a, _ = m.Step(9)
+    m.Reset()
+    b, _ = m.Step(9)
+    np.testing.assert_array_equal(a, b)
+    m.Dispose()
+    five.Dispose()
+
+
+@pytest.mark.parametrize("dims", [synth.LLAMA_32_1B, synth.LLAMA_32_3B, synth.LLAMA_31_8B], ids=lambda d: d.name)
+def test_engine_two_full_width_blocks(mgr, dims):
+    """Two blocks at the published widths of each BASELINE model (the first engine launch carries the second block's q|k|v,
+    the last one ends with Wdown), vocabulary cut to 4096 rows, 16 positions, against the oracle."""
+    from dataclasses import replace
+    from nfai_amd.llama_model import LlamaModel
+    d2 = replace(dims, L=2, V=4096, name=dims.name + "-2blk")
+    w = synth.make_weights(d2, seed=93)
+    m = LlamaModel(mgr, synth.make_metadata(d2), w, 24, engine=True)
+    ref = orc.OracleLlama(odesc(d2, 24), w)
+    for t in synth.make_tokens(d2, 16, seed=15):
+        lg, am = m.Step(int(t))
+        want = ref.step(int(t))
+        assert np.abs(lg - want).max() <= logit_tol(want), np.abs(lg - want).max()
+    np.testing.assert_allclose(m.Read(0, d2.E), ref.hidden(), rtol=0, atol=1e-3)
+    m.Dispose()
+
+
+def test_engine_pipeline_stages_and_fallback(mgr):
+    """Layer ranges as stages with the engine on: bit-identical to the whole model with the engine on.  A model the engine
+    cannot take (K not a multiple of 512) silently runs the five-launch path."""
+    from nfai_amd.hip import ShaderProperty
+    from nfai_amd.llama_model import LlamaModel
+    dims = synth.TINY_D128
+    w = synth.make_weights(dims, seed=95, std=0.05)
+    md = synth.make_metadata(dims)
+    whole = LlamaModel(mgr, md, w, 16, engine=True)
+    s0 = LlamaModel(mgr, md, w, 16, layer_range=(0, 2), engine=True)
+    s1 = LlamaModel(mgr, md, w, 16, layer_range=(2, 3), engine=True)
+    h01 = ShaderProperty(mgr, dims.E)
+    for t in (4, 8, 15, 16, 23, 42):
+        want, am = whole.Step(t)
+        s0.StageStep(t, None, h01.buffer.device_ptr)
+        lg, am2 = s1.StageStep(0, h01.buffer.device_ptr, None, want_logits=True)
+        np.testing.assert_array_equal(lg, want)
+        assert am == am2
+    for m in (whole, s0, s1):
+        m.Dispose()
+    tiny = synth.TINY  # E = 256
+    wt = synth.make_weights(tiny, seed=96, std=0.05)
+    a = LlamaModel(mgr, synth.make_metadata(tiny), wt, 8, engine=True)
+    b = LlamaModel(mgr, synth.make_metadata(tiny), wt, 8, engine=False)
+    np.testing.assert_array_equal(a.Step(3)[0], b.Step(3)[0])
+    a.Dispose()
+    b.Dispose()
