@@ -213,8 +213,12 @@ __device__ __forceinline__ void eng_consumer(const EngineParams &p, uint8_t *lds
     const float *XR = reinterpret_cast<const float *>(lds + p.xr_off);
     uint32_t rel = 0;     // slot sequence numbers [0, rel) released by this wave
     uint32_t gbase = 0;   // first piece of the current op
-    auto release_below = [&](uint32_t S) {
-        for (; rel < S; rel++) lds_add(W_FREE + (rel % nslot) * 4, 1);
+    uint32_t rel_s = 0;   // rel % nslot
+    auto release_below = [&](uint32_t S) {  // one lane adds: a wave-wide ds_add would count 64
+        for (; rel < S; rel++) {
+            if (lane == 0) lds_add(W_FREE + rel_s * 4, 1);
+            if (++rel_s == nslot) rel_s = 0;
+        }
     };
     const uint32_t pos = p.pos ? ((const GLOBAL_AS uint32_t *)p.pos)[0] : 0u;
     bool ok = true;
