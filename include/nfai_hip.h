@@ -178,6 +178,18 @@ int32_t nfai_hip_gemv_qkv_rope(nfai_ctx_t ctx, nfai_buf_t Wq, nfai_buf_t Wk, nfa
                                uint32_t rope_dims, nfai_buf_t q, nfai_buf_t kcache, nfai_buf_t vcache,
                                uint32_t H, uint32_t Hkv, uint32_t D, uint32_t pos, int32_t kv_type, uint32_t E);
 
+/* Wo + residual -> RMSNorm + Wgate|Wup + SiLU*up -> Wdown + residual [-> RMSNorm + next block's Wq|Wk|Wv + RoPE + KV write] of one
+ * TransformerBlock (TransformerBlock.cs:150-181, then :129-141 of the next block) as ONE launch of the weight-streaming engine
+ * (kernels_engine.hip), fp16 weights, E / F / HD multiples of 512, on caller-held buffers: the op-level form of what the model
+ * enqueues per block under NFAI_LLAMA_ENGINE.  Wq == 0: the launch ends with Wdown.  K/V caches in the reference layout
+ * [C][Hkv*D].  scratch: (2E + F) * 8 + 64 bytes, zeroed once by the caller (hand-off granules {value, tag} of h | act | x, then
+ * control words). */
+int32_t nfai_hip_engine_block(nfai_ctx_t ctx, nfai_buf_t Wo, nfai_buf_t Wgate, nfai_buf_t Wup, nfai_buf_t Wdown, nfai_buf_t att,
+                              nfai_buf_t x_in, nfai_buf_t gamma_ffn, float eps, uint32_t E, uint32_t F, uint32_t HD,
+                              nfai_buf_t Wq, nfai_buf_t Wk, nfai_buf_t Wv, nfai_buf_t gamma_next, nfai_buf_t freqs,
+                              uint32_t rope_dims, nfai_buf_t q_out, nfai_buf_t kcache, nfai_buf_t vcache, uint32_t H, uint32_t Hkv,
+                              uint32_t D, uint32_t pos, int32_t kv_type, nfai_buf_t x_out, nfai_buf_t scratch);
+
 /* ---- model level: replaces LlamaModel (graph LlamaModel.cs:21-68, token loop :99-174) and
  *      TransformerBlock (wiring TransformerBlock.cs:31-125, sequence :127-184). ---- */
 enum nfai_llama_flags {

@@ -809,6 +809,97 @@ NFAI_API int32_t nfai_hip_gemv_qkv_rope(nfai_ctx_t h, nfai_buf_t Wq, nfai_buf_t 
     return gemv_common(c, a, __func__);
 }
 
+// One launch of the weight-streaming engine on caller-held buffers (tests / tools): what nfai_hip_llama_* enqueues per block when
+// NFAI_LLAMA_ENGINE is set.  `scratch` holds the hand-off granules h (E) | act (F) | x (E) (8 bytes each: value, tag) followed by
+// 64 bytes of control words (epoch, error); the caller zeroes it once and may read the granules' low words afterwards.
+NFAI_API int32_t nfai_hip_engine_block(nfai_ctx_t h, nfai_buf_t Wo, nfai_buf_t Wgate, nfai_buf_t Wup, nfai_buf_t Wdown, nfai_buf_t att,
+                                       nfai_buf_t x_in, nfai_buf_t gamma_ffn, float eps, uint32_t E, uint32_t F, uint32_t HD,
+                                       nfai_buf_t Wq, nfai_buf_t Wk, nfai_buf_t Wv, nfai_buf_t gamma_next, nfai_buf_t freqs,
+                                       uint32_t rope_dims, nfai_buf_t q_out, nfai_buf_t kc, nfai_buf_t vc, uint32_t H, uint32_t Hkv,
+                                       uint32_t D, uint32_t pos, int32_t kv_type, nfai_buf_t x_out, nfai_buf_t scratch)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(bwo, Wo);
+    BUF_OR_FAIL(bwg, Wgate);
+    BUF_OR_FAIL(bwu, Wup);
+    BUF_OR_FAIL(bwd, Wdown);
+    BUF_OR_FAIL(batt, att);
+    BUF_OR_FAIL(bx, x_in);
+    BUF_OR_FAIL(bg, gamma_ffn);
+    BUF_OR_FAIL(bxo, x_out);
+    BUF_OR_FAIL(bs, scratch);
+    if (E % 512 || F % 512 || HD % 512) return fail(NFAI_ERR_INVALID, "engine_block: E, F, H*D must be multiples of 512");
+    NEED(bwo, (uint64_t)E * HD, 2);
+    NEED(bwg, (uint64_t)F * E, 2);
+    NEED(bwu, (uint64_t)F * E, 2);
+    NEED(bwd, (uint64_t)E * F, 2);
+    NEED(batt, HD, 4);
+    NEED(bx, E, 4);
+    NEED(bg, E, 4);
+    NEED(bxo, E, 4);
+    const uint64_t ngran = 2ull * E + F;
+    NEED(bs, ngran * 8 + 64, 1);
+    uint64_t *gr = static_cast<uint64_t *>(bs->ptr);
+    uint32_t *words = reinterpret_cast<uint32_t *>(gr + ngran);
+    EngineArgs e;
+    e.E = E; e.F = F; e.HD = HD;
+    e.Wo = bwo->ptr; e.Wgate = bwg->ptr; e.Wup = bwu->ptr; e.Wdown = bwd->ptr;
+    e.att = static_cast<const float *>(batt->ptr);
+    e.x_in = static_cast<const float *>(bx->ptr);
+    e.gamma_ffn = static_cast<const float *>(bg->ptr);
+    e.eps = eps;
+    e.g_h = gr; e.g_act = gr + E; e.g_x = gr + E + F;
+    e.epoch = words; e.err = words + 1;
+    e.x_out = static_cast<float *>(bxo->ptr);
+    e.n_cu = (uint32_t)c->prop.multiProcessorCount;
+    e.n_ops = 3;
+    const float *fr = nullptr;
+    uint32_t nfreq = 0;
+    if (Wq) {
+        BUF_OR_FAIL(bq_, Wq);
+        BUF_OR_FAIL(bk_, Wk);
+        BUF_OR_FAIL(bv_, Wv);
+        BUF_OR_FAIL(bgn, gamma_next);
+        BUF_OR_FAIL(bf, freqs);
+        BUF_OR_FAIL(bq, q_out);
+        BUF_OR_FAIL(bk, kc);
+        BUF_OR_FAIL(bv, vc);
+        if (kv_type != NFAI_F32 && kv_type != NFAI_F16) return fail(NFAI_ERR_UNSUPPORTED, "engine_block: kv type %d", kv_type);
+        const uint32_t esz = kv_type == NFAI_F16 ? 2 : 4;
+        nfreq = (rope_dims < D ? rope_dims : D) / 2;
+        NEED(bq_, (uint64_t)H * D * E, 2);
+        NEED(bk_, (uint64_t)Hkv * D * E, 2);
+        NEED(bv_, (uint64_t)Hkv * D * E, 2);
+        NEED(bgn, E, 4);
+        NEED(bf, nfreq, 4);
+        NEED(bq, (uint64_t)H * D, 4);
+        NEED(bk, ((uint64_t)pos + 1) * Hkv * D, esz);
+        NEED(bv, ((uint64_t)pos + 1) * Hkv * D, esz);
+        if (nfreq * 8 > 3072) return fail(NFAI_ERR_INVALID, "engine_block: rope_dims too large");
+        e.n_ops = 4;
+        e.Wqkv[0] = bq_->ptr; e.Wqkv[1] = bk_->ptr; e.Wqkv[2] = bv_->ptr;
+        e.qkv_rows[0] = H * D; e.qkv_rows[1] = Hkv * D; e.qkv_rows[2] = Hkv * D;
+        e.gamma_next = static_cast<const float *>(bgn->ptr);
+        e.q_out = static_cast<float *>(bq->ptr);
+        e.kcache = bk->ptr; e.vcache = bv->ptr; e.kv_type = kv_type;
+        e.kv_pos_stride = (uint64_t)Hkv * D; e.kv_head_stride = D;   // reference layout [C][Hkv*D]
+        e.rope_cs = scratch_ropecs(c); e.rope_dims = rope_dims; e.D = D;
+        e.pos_dev = scratch_pos(c);
+        fr = static_cast<const float *>(bf->ptr);
+        HIP_TRY(hipMemcpyAsync(scratch_pos(c), &pos, 4, hipMemcpyHostToDevice, c->stream));
+    }
+    // cos/sin table of the position (when q|k|v is on) and the epoch of this call's hand-offs
+    LAUNCH_TRY(launch_token_begin(nullptr, 0, nullptr, nullptr, 0, fr, scratch_ropecs(c), nfreq, scratch_pos(c), c->stream, words));
+    hipError_t le = launch_engine(e, c->stream);
+    if (le == hipErrorInvalidValue) return fail(NFAI_ERR_INVALID, "engine_block: unsupported shape (E=%u F=%u HD=%u)", E, F, HD);
+    if (le != hipSuccess) return fail(NFAI_ERR_HIP, "engine_block: launch failed: %s", hipGetErrorString(le));
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpyAsync(&err, words + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (err) return fail(NFAI_ERR_HIP, "engine_block: a bounded wait inside the launch gave up (code 0x%x)", err);
+    return NFAI_OK;
+}
+
 #ifdef NFAI_STAMPS
 // Not part of include/nfai_hip.h: exists only in libnfai_hip_stamps.so (tools/stamps.py binds it by name).
 NFAI_API int32_t nfai_hip_debug_stamps_install(void *buf, uint32_t n_slots)

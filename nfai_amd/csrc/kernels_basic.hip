@@ -307,7 +307,7 @@ hipError_t launch_token_begin(const void *table, int type, const uint32_t *tok, 
                               const float *freqs, float *rope_cs, uint32_t n_freq, const uint32_t *pos_dev,
                               hipStream_t s, uint32_t *epoch)
 {
-    const uint32_t n = E > n_freq ? E : n_freq;
+    const uint32_t n = (E > n_freq ? E : n_freq) > 0 ? (E > n_freq ? E : n_freq) : 1;  // at least one block: the epoch word
     k_token_begin<<<(n + 255) / 256, 256, 0, s>>>(table, type, tok, x, E, freqs, rope_cs, n_freq, pos_dev, epoch);
     return hipGetLastError();
 }

@@ -17,7 +17,7 @@
 //               ONE consumer wave, so a row is reduced inside a wave (DPP) and its epilogue needs nobody else
 //   op        = one projection; the CU owns a contiguous range of its units; the pieces of all ops form ONE flat sequence
 //               through the ring, so the loader is already fetching the next projection while this one waits for its input
-//   slot      = 8 pieces; loader -> consumers: full_gen[slot] behind a counted vmcnt; consumers -> loader: free_cnt[slot]
+//   slot      = 8 pieces; loader -> consumers: full_gen[slot] behind a counted vmcnt; consumers -> loader: a release mark per consumer
 //               after their reads are in registers (MI355X guide, ring-gemm: a FULL word per loader, a FREE word per consumer)
 //
 // Numerics: the same fp16-weight x fp32-activation FMAs and fp32 epilogues as kernels_gemv.hip (RMSNorm as RMSNormShader.cs:
@@ -89,7 +89,18 @@ __device__ __forceinline__ uint32_t lds_ld(uint32_t addr)
 __device__ __forceinline__ void lds_st(uint32_t addr, uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 __device__ __forceinline__ void lds_add(uint32_t addr, uint32_t v) { asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 
-constexpr uint32_t W_ABORT = 0, W_XREADY = 4, W_DONE = 8, W_FULL = 64, W_FREE = 128;  // byte offsets of the control words
+constexpr uint32_t W_ABORT = 0, W_XREADY = 4, W_DONE = 8, W_REL = 16, W_FULL = 64;  // byte offsets of the control words
+// W_REL: one word per consumer wave (16-byte aligned block of ENG_NC words): slot sequence numbers [0, rel) are released by it.
+// W_FULL: one word per ring slot: generation (+1) whose pieces have landed.
+
+// the smallest of the four consumers' release marks (one ds_read_b128), wave-uniform
+__device__ __forceinline__ uint32_t lds_ld_min4(uint32_t addr)
+{
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+    const uint32_t a = min(min(v[0], v[1]), min(v[2], v[3]));
+    return __builtin_amdgcn_readfirstlane(a);
+}
 
 // bounded wait until the LDS word at `addr` is >= target; false on abort / timeout
 __device__ __forceinline__ bool lds_wait_ge(uint32_t addr, uint32_t target, uint32_t *err, uint32_t code)
@@ -142,52 +153,79 @@ __device__ __forceinline__ uint32_t eng_xs_index(uint32_t k)
 }
 
 // ---- loader wave: the flat piece sequence of all ops into the ring -------------------------------------------------------
+// Piece order inside an op: the CU's units are taken four at a time (a "quad": one unit per consumer wave); inside a quad the
+// rows advance together, eight pieces at a time: for sub-row 0/1, for each group of <= 8 chunks, for consumer 0..3.  So the four
+// consumers walk the ring side by side whatever the row length (a Wdown row of Llama-3.1-8B alone is 28 KiB).
+//   offset of (sub, c0, w) inside a quad of nuq units = (sub * KC + c0) * nuq + w * min(8, KC - c0)
 template <int AHEAD>
 __device__ __forceinline__ void eng_loader(const EngineParams &p, uint8_t *lds, uint32_t lane)
 {
     const uint32_t nslot = p.nslot, ring_pieces = nslot * ENG_SLOT;
-    // position of the next piece (all wave-uniform): ring index rp, slot s of generation gen, `within` pieces of it issued
-    uint32_t rp = 0, s = 0, gen = 0, within = 0;
-    uint32_t seq = 0;           // slot sequence number being filled (= gen * nslot + s)
+    // position of the next piece (all wave-uniform): ring index rp, `within` pieces of the current slot issued
+    uint32_t rp = 0, within = 0;
+    uint32_t seq = 0;           // slot sequence number being filled
     uint32_t published = 0;     // slot sequence numbers [0, published) are marked full
     uint32_t ps = 0, pgen = 0;  // slot / generation of sequence number `published`
     LDS_AS uint8_t *ring = (LDS_AS uint8_t *)(lds + p.ring_off);
     bool ok = true;
+    // n consecutive pieces of one row, split where they cross a slot boundary
+    auto issue = [&](const GLOBAL_AS uint8_t *src, uint32_t n) {
+        while (n && ok) {
+            if (within == 0 && seq >= nslot) {  // a new slot: every consumer must have released its previous occupant (seq - nslot)
+                const uint32_t need = seq - nslot + 1;
+                for (uint32_t spins = 0; (int32_t)(lds_ld_min4(W_REL) - need) < 0; spins++) {
+                    if (lds_ld(W_ABORT) != 0) { ok = false; break; }
+                    if (spins > ENG_SPIN_CAP) {
+                        lds_st(W_ABORT, 1);
+                        if (lane == 0) __hip_atomic_fetch_or(p.err, 0x10u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (!ok) break;
+            }
+            const uint32_t run = min(n, (uint32_t)ENG_SLOT - within);
+            for (uint32_t j = 0; j < run; j++) {
+                __builtin_amdgcn_global_load_lds(src, ring + (rp + j) * 1024, 16, 0, 2);  // aux 2 = nt
+                src += 1024;
+            }
+            n -= run;
+            rp += run;
+            within += run;
+            if (within == ENG_SLOT) {  // slot `seq` issued completely: the slot AHEAD behind it has landed
+                within = 0;
+                if (rp == ring_pieces) rp = 0;
+                if (seq >= (uint32_t)AHEAD) {
+                    eng_wait_vmcnt<ENG_SLOT * AHEAD>();
+                    lds_st(W_FULL + ps * 4, pgen + 1);
+                    published++;
+                    if (++ps == nslot) { ps = 0; pgen++; }
+                }
+                seq++;
+            }
+        }
+    };
     for (uint32_t oi = 0; oi < p.n_ops && ok; oi++) {
         const EngOp &o = p.op[oi];
         uint32_t ub, ue;
         eng_unit_range(o.NU, ub, ue);
-        const uint32_t KC = o.K >> 9;
-        for (uint32_t u = ub; u < ue && ok; u++) {
-            for (uint32_t sub = 0; sub < 2 && ok; sub++) {
-                const GLOBAL_AS uint8_t *src = eng_row(o, u, sub) + lane * 16;
-                for (uint32_t c = 0; c < KC;) {
-                    if (within == 0 && gen > 0) {  // a new slot: every consumer must have released its previous generation
-                        if (!lds_wait_ge(W_FREE + s * 4, ENG_NC * gen, p.err, 0x10u)) { ok = false; break; }
-                    }
-                    // a run of pieces of this row inside the current slot: nothing to check between them
-                    const uint32_t run = min(KC - c, (uint32_t)ENG_SLOT - within);
-                    for (uint32_t j = 0; j < run; j++) {
-                        __builtin_amdgcn_global_load_lds(src, ring + (rp + j) * 1024, 16, 0, 2);  // aux 2 = nt
-                        src += 1024;
-                    }
-                    c += run;
-                    rp += run;
-                    within += run;
-                    if (within == ENG_SLOT) {  // slot `seq` issued completely: the slot AHEAD behind it has landed
-                        within = 0;
-                        if (rp == ring_pieces) rp = 0;
-                        if (seq >= (uint32_t)AHEAD) {
-                            eng_wait_vmcnt<ENG_SLOT * AHEAD>();
-                            lds_st(W_FULL + ps * 4, pgen + 1);
-                            published++;
-                            if (++ps == nslot) { ps = 0; pgen++; }
-                        }
-                        seq++;
-                        if (++s == nslot) { s = 0; gen++; }
-                    }
+        const uint32_t KC = o.K >> 9, nu = ue - ub;
+        for (uint32_t q0 = 0; q0 < nu && ok; q0 += ENG_NC) {
+            const uint32_t nuq = min((uint32_t)ENG_NC, nu - q0);
+            const GLOBAL_AS uint8_t *rows[ENG_NC][2];
+#pragma unroll
+            for (int w = 0; w < ENG_NC; w++)
+#pragma unroll
+                for (int sub = 0; sub < 2; sub++) rows[w][sub] = eng_row(o, ub + q0 + min((uint32_t)w, nuq - 1), sub) + lane * 16;
+#pragma unroll
+            for (int sub = 0; sub < 2; sub++)
+                for (uint32_t c0 = 0; c0 < KC; c0 += 8) {
+                    const uint32_t n = min(8u, KC - c0);
+#pragma unroll
+                    for (int w = 0; w < ENG_NC; w++)
+                        if ((uint32_t)w < nuq) issue(rows[w][sub] + (uint64_t)c0 * 1024, n);
                 }
-            }
         }
     }
     // drain: everything issued has landed; publish the remaining slots (the last one may be partial)
@@ -213,11 +251,10 @@ __device__ __forceinline__ void eng_consumer(const EngineParams &p, uint8_t *lds
     const float *XR = reinterpret_cast<const float *>(lds + p.xr_off);
     uint32_t rel = 0;     // slot sequence numbers [0, rel) released by this wave
     uint32_t gbase = 0;   // first piece of the current op
-    uint32_t rel_s = 0;   // rel % nslot
-    auto release_below = [&](uint32_t S) {  // one lane adds: a wave-wide ds_add would count 64
-        for (; rel < S; rel++) {
-            if (lane == 0) lds_add(W_FREE + rel_s * 4, 1);
-            if (++rel_s == nslot) rel_s = 0;
+    auto release_below = [&](uint32_t S) {  // this wave will not read slot sequence numbers < S again
+        if (S > rel) {
+            rel = S;
+            lds_st(W_REL + w * 4, rel);
         }
     };
     const uint32_t pos = p.pos ? ((const GLOBAL_AS uint32_t *)p.pos)[0] : 0u;
@@ -228,11 +265,12 @@ __device__ __forceinline__ void eng_consumer(const EngineParams &p, uint8_t *lds
         eng_unit_range(o.NU, ub, ue);
         const uint32_t KC = o.K >> 9, nu = ue - ub;
         // nothing before this wave's first piece of the op will be read by it again
-        release_below((gbase + (w < nu ? w : nu) * 2 * KC) / ENG_SLOT);
+        release_below((gbase + (w < nu ? w * min(8u, KC) : nu * 2 * KC)) / ENG_SLOT);
         if (!lds_wait_ge(W_XREADY, oi + 1, p.err, 0x20u)) { ok = false; break; }
         const float *xs = reinterpret_cast<const float *>(lds + (o.x_sel ? p.xb_off : p.xa_off));
-        for (uint32_t ul = w; ul < nu && ok; ul += ENG_NC) {
-            const uint32_t u = ub + ul;
+        for (uint32_t q0 = 0; q0 + w < nu && ok; q0 += ENG_NC) {
+            const uint32_t nuq = min((uint32_t)ENG_NC, nu - q0), qbase = gbase + q0 * 2 * KC;
+            const uint32_t u = ub + q0 + w;
             // what the epilogue reads from memory is requested now (RoPE pair)
             float cs0 = 1.f, cs1 = 0.f;
             uint32_t seg = 0, r = 0;
@@ -248,10 +286,10 @@ __device__ __forceinline__ void eng_consumer(const EngineParams &p, uint8_t *lds
             float acc[2] = {0.f, 0.f};
 #pragma unroll
             for (int sub = 0; sub < 2; sub++) {
-                const uint32_t gp = gbase + (ul * 2 + sub) * KC;
                 float a = 0.f;
                 for (uint32_t c0 = 0; c0 < KC && ok; c0 += 8) {
-                    const uint32_t n = min(8u, KC - c0), gfirst = gp + c0, glast = gfirst + n - 1;
+                    const uint32_t n = min(8u, KC - c0);
+                    const uint32_t gfirst = qbase + ((uint32_t)sub * KC + c0) * nuq + w * n, glast = gfirst + n - 1;
                     release_below(gfirst / ENG_SLOT);
                     const uint32_t S = glast / ENG_SLOT, Sgen = S / nslot;
                     if (!lds_wait_ge(W_FULL + (S - Sgen * nslot) * 4, Sgen + 1, p.err, 0x40u)) { ok = false; break; }
@@ -308,7 +346,7 @@ __device__ __forceinline__ void eng_consumer(const EngineParams &p, uint8_t *lds
         gbase += nu * 2 * KC;
         if (lane == 0) lds_add(W_DONE, 1);  // this wave's outputs of the op are on their way
     }
-    release_below((gbase + ENG_SLOT - 1) / ENG_SLOT + nslot);  // harmless surplus: the loader has finished
+    release_below((gbase + ENG_SLOT - 1) / ENG_SLOT);
 }
 
 // ---- control wave: gathers ------------------------------------------------------------------------------------------------
@@ -346,7 +384,8 @@ __device__ __forceinline__ bool eng_gather(const uint64_t *g, uint32_t n, uint32
         for (int k = 0; k < 8; k++) {
             if ((uint32_t)k < nl) {
                 const uint32_t e = ((l0 + k) * 64 + lane) * 2;  // element index of the first of the two granules
-                const float a = __builtin_bit_cast(float, v[k][0]), b = __builtin_bit_cast(float, v[k][2]);
+                const f32x4 vf = __builtin_bit_cast(f32x4, v[k]);  // whole-vector cast (on an ELEMENT lvalue hipcc 7.2 reads element 0)
+                const float a = vf[0], b = vf[2];
                 ss = fmaf(a, a, ss);
                 ss = fmaf(b, b, ss);
                 const uint32_t i = PERMUTE ? eng_xs_index(e) : e;  // e is even: the pair stays adjacent under the permutation

@@ -488,3 +488,83 @@ def test_gemm_f16_causal_attention_pair(mgr, variant, pos0):
     for h in range(H):
         want = P[h].astype(np.float64) @ Vt[h // G].astype(np.float64).T
         assert np.abs(att[h] - want).max() <= 2e-3 * np.abs(want).max() + 1e-4, (h, np.abs(att[h] - want).max())
+
+
+def _rms(x, g, eps=1e-5):
+    x = x.astype(np.float64)
+    return (x / np.sqrt((x * x).mean() + eps)) * g.astype(np.float64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("E,F,H,Hkv,D,with_qkv", [(512, 1024, 4, 2, 128, True), (512, 1024, 4, 2, 128, False), (2048, 8192, 32, 8, 64, True),
+                                                  (3072, 8192, 24, 8, 128, True), (4096, 14336, 32, 8, 128, True)],
+                         ids=["tiny", "tiny-no-qkv", "1b", "3b", "8b"])
+def test_engine_block_op_level(mgr, E, F, H, Hkv, D, with_qkv):
+    """One launch of the weight-streaming engine against fp64 NumPy, stage by stage (the hand-off vectors h and act are read back
+    from the granules): Wo + residual, RMSNorm + gate|up + SiLU*up, Wdown + residual, RMSNorm + next q|k|v + RoPE + KV rows
+    (TransformerBlock.cs:150-181, :129-141).  fp32 summation-order tolerances as for the GEMV family; two calls bit-equal."""
+    from nfai_amd._lib import call
+    from nfai_amd.hip import ShaderProperty
+    r = rng(E + F + int(with_qkv))
+    HD, KD = H * D, Hkv * D
+    def mat(n, k, s=0.02):
+        return (s * r.standard_normal((n, k))).astype(np.float16)
+    Wo, Wg, Wu, Wd = mat(E, HD), mat(F, E), mat(F, E), mat(E, F)
+    Wq, Wk, Wv = mat(HD, E), mat(KD, E), mat(KD, E)
+    att = r.standard_normal(HD).astype(np.float32)
+    x = r.standard_normal(E).astype(np.float32)
+    g1 = (1 + 0.1 * r.standard_normal(E)).astype(np.float32)
+    g2 = (1 + 0.1 * r.standard_normal(E)).astype(np.float32)
+    pos = 5
+    freqs = (1.0 / 500000.0 ** (np.arange(D // 2) / (D / 2))).astype(np.float32)
+    def up(a, dt):
+        p = ShaderProperty(mgr, a.size, dt)
+        p.SetValue(a.ravel())
+        return p
+    pWo, pWg, pWu, pWd = (up(a, np.float16) for a in (Wo, Wg, Wu, Wd))
+    pWq, pWk, pWv = (up(a, np.float16) for a in (Wq, Wk, Wv))
+    patt, px, pg1, pg2, pfr = (up(a, np.float32) for a in (att, x, g1, g2, freqs))
+    pxo, pq = ShaderProperty(mgr, E), ShaderProperty(mgr, HD)
+    pkc, pvc = ShaderProperty(mgr, (pos + 1) * KD), ShaderProperty(mgr, (pos + 1) * KD)
+    nwords = (2 * E + F) * 2 + 16
+    psc = ShaderProperty(mgr, nwords, np.uint32)
+    psc.SetValue(np.zeros(nwords, np.uint32))
+    def run():
+        q = (pWq.handle, pWk.handle, pWv.handle, pg2.handle, pfr.handle) if with_qkv else (0, 0, 0, 0, 0)
+        o = (pq.handle, pkc.handle, pvc.handle) if with_qkv else (0, 0, 0)
+        call("nfai_hip_engine_block", mgr.handle, pWo.handle, pWg.handle, pWu.handle, pWd.handle, patt.handle, px.handle, pg1.handle,
+             1e-5, E, F, HD, *q, D, *o, H, Hkv, D, pos, 0, pxo.handle, psc.handle)
+        return pxo.GetValue().copy(), psc.GetValue().copy()
+    xo, sc = run()
+    gran = sc[: (2 * E + F) * 2].reshape(-1, 2)
+    vals = gran[:, 0].copy().view(np.float32)
+    assert (gran[: E + F, 1] == 1).all()  # every granule of h and act carries the first call's epoch
+    f64 = np.float64
+    h = x.astype(f64) + Wo.astype(f64) @ att.astype(f64)
+    xa = _rms(h, g1)
+    gate, upv = Wg.astype(f64) @ xa, Wu.astype(f64) @ xa
+    act = upv * _silu64(gate)
+    want_x = h + Wd.astype(f64) @ act
+    tol_h = gemv_tol(Wo, att).max() + 1e-6
+    assert np.abs(vals[:E] - h).max() <= tol_h, np.abs(vals[:E] - h).max()
+    assert np.abs(vals[E:E + F] - act).max() <= 2e-5 * max(1.0, np.abs(act).max()), np.abs(vals[E:E + F] - act).max()
+    assert np.abs(xo - want_x).max() <= 5e-5 * max(1.0, np.abs(want_x).max()), np.abs(xo - want_x).max()
+    if with_qkv:
+        assert (gran[E + F:, 1] == 1).all()
+        np.testing.assert_array_equal(vals[E + F:], xo)  # the granule copy and the plain copy of the block output
+        xn = _rms(want_x, g2)
+        qkv = np.concatenate([Wq, Wk, Wv]).astype(f64) @ xn
+        th = freqs.astype(f64) * pos
+        def rope(v, nh):
+            v = v.reshape(nh, D // 2, 2).copy()
+            a, b = v[..., 0].copy(), v[..., 1].copy()
+            v[..., 0] = a * np.cos(th) - b * np.sin(th)
+            v[..., 1] = a * np.sin(th) + b * np.cos(th)
+            return v.reshape(-1)
+        tol = 1e-4 * max(1.0, np.abs(qkv).max())
+        assert np.abs(pq.GetValue() - rope(qkv[:HD], H)).max() <= tol
+        assert np.abs(pkc.GetValue()[pos * KD:] - rope(qkv[HD:HD + KD], Hkv)).max() <= tol
+        assert np.abs(pvc.GetValue()[pos * KD:] - qkv[HD + KD:]).max() <= tol
+    xo2, sc2 = run()  # second call: epoch 2, same values bit for bit
+    np.testing.assert_array_equal(xo, xo2)
+    assert (sc2[: (E + F) * 2].reshape(-1, 2)[:, 1] == 2).all()
