@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-mfma-prefill", action="store_true", help="fill the context through the decode path")
     ap.add_argument("--profile-steps", type=int, default=6)
+    ap.add_argument("--engine", type=int, default=-1, help="1 / 0: one weight-streaming engine launch per block / the five-launch path (-1 = library default)")
     return ap.parse_args()
 
 
@@ -190,7 +191,7 @@ def run_single(args):
     mgr = HipBufferManager(0)
     C = args.context + args.warmup + args.steps
     m = LlamaModel(mgr, synth.make_metadata(dims), as_model_tensors(_lib, weights), C,
-                   graph=not args.no_graph, kv_f16=args.kv_f16, max_batch=args.context, dims=dict(
+                   graph=not args.no_graph, kv_f16=args.kv_f16, max_batch=args.context, engine=(None if args.engine < 0 else bool(args.engine)), dims=dict(
                        E=dims.E, L=dims.L, H=dims.H, Hkv=dims.Hkv, D=dims.D, F=dims.F, V=dims.V, eps=1e-5,
                        rope_dims=dims.D, rope_base=500000.0))
     first_token = 128000 % dims.V
@@ -259,8 +260,24 @@ def run_single(args):
             a = prof.setdefault(k, [0.0, 0])
             a[0] += ms
             a[1] += n
-    # HBM traffic of the dominant kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
-    # passes, gfx950 correction applied): collected offline on the same build, committed under profiles/
+    # the dominant kernel's duration: its launches of one step (one per block, each streaming its own weights) replayed back
+    # to back, 4 rounds, inside ONE event pair on the launch stream — what rocprofv3 --kernel-trace reports per launch (the
+    # per-launch event pairs above add ~2.5 us of launch overhead each)
+    if m.Pos >= C:
+        m.SetPos(pos0)
+    engine_on = bool(prof) and prof.get("engine", (0.0, 0))[1] > 0
+    if engine_on:
+        # one engine launch per block: Wo + gate|up + Wdown of the block and q|k|v of the next one (the last block has none)
+        bpw = 2 if args.quant == "f16" else None
+        HD, KD = dims.H * dims.D, dims.Hkv * dims.D
+        dom_bytes = (dims.E * HD + 3 * dims.F * dims.E) * bpw + (dims.L - 1) * (HD + 2 * KD) * dims.E * bpw // dims.L
+        dom_cls, dom_name = "engine", "k_engine (Wo + residual -> RMSNorm + gate|up + SiLU*up -> Wdown + residual -> RMSNorm + next q|k|v + RoPE, one launch per block)"
+        pmc_key = "nfai::k_engine"
+    else:
+        dom_cls = "gateup"
+        dom_name = ("k_gemv<F16,GATEUP>" if args.quant == "f16" else "k_gemv_kqt<Q4_K_T16,GATEUP> int8-MFMA") + " (RMSNorm + Wgate/Wup GEMV + SiLU*up)"
+    # HBM traffic of the dominant kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes, gfx950
+    # correction applied): collected offline on the same build by tools/pmc_traffic.py, committed under profiles/
     traffic, traffic_source = None, None
     if args.model == "llama-3.2-3b":
         tag = "" if args.quant == "f16" else "_q4km"
@@ -268,6 +285,8 @@ def run_single(args):
             f = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic{tag}.json")
             try:
                 pmc = json.load(open(f))
+                if bool(pmc.get("engine", False)) != engine_on:
+                    continue  # counters of the other launch structure
                 k = pmc.get("dominant_kernel") or ("nfai::k_gemv<1, 3, 2, 3, false, true>" if args.quant == "f16" else "nfai::k_gemv_kqt<112, 3, 1, true, 0>")
                 traffic = pmc["kernels"][k]["hbm_bytes_per_launch"]
                 traffic_source = (f"profiles/{os.path.basename(f)}: separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over `{pmc.get('command', '?')}`, "
@@ -275,13 +294,8 @@ def run_single(args):
                 break
             except (OSError, KeyError, ValueError):
                 continue
-    gu_eager_ms = prof["gateup"][0] / max(1, prof["gateup"][1]) if prof else float("nan")
-    # the dominant kernel's duration: its launches of one step (one per block, each streaming its own weights) replayed back
-    # to back, 4 rounds, inside ONE event pair on the launch stream — what rocprofv3 --kernel-trace reports per launch (the
-    # per-launch event pairs above add ~2.5 us of launch overhead each)
-    if m.Pos >= C:
-        m.SetPos(pos0)
-    gu_ms = m.ProfileKernel(int(toks[-1]), "gateup", 4) * 1e-3
+    gu_eager_ms = prof[dom_cls][0] / max(1, prof[dom_cls][1]) if prof else float("nan")
+    gu_ms = m.ProfileKernel(int(toks[-1]), dom_cls, 4) * 1e-3
     achieved = dom_bytes / (gu_ms * 1e-3) / 1e9
     per_kernel_us = {k: round(1e3 * v[0] / v[1], 3) for k, v in prof.items() if v[1]}
     out = {
@@ -292,10 +306,10 @@ def run_single(args):
         "config": {"workload": f"{dims.name} {'fp16-GGUF weights (fp16 in HBM)' if args.quant == 'f16' else 'Q4_K_M-GGUF weights (native K-quant blocks in HBM)'}, fp32 activations + {'fp16' if args.kv_f16 else 'fp32'} KV, "
                                f"batch-1 greedy decode of {args.steps} tokens after a {args.context}-token context",
                    "positions": [pos0, pos0 + args.steps - 1], "kv_capacity": C, "parallelism": "single",
-                   "graph": not args.no_graph},
+                   "graph": not args.no_graph, "launches_per_block": 2 if engine_on else 5},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": ("k_gemv<F16,GATEUP>" if args.quant == "f16" else "k_gemv_kqt<Q4_K_T16,GATEUP> int8-MFMA") + " (RMSNorm + Wgate/Wup GEMV + SiLU*up)",
+                     "kernel": dom_name,
                      "bytes_per_launch": dom_bytes, "us_per_launch": gu_ms * 1e3, "us_per_launch_eager_event_pair": gu_eager_ms * 1e3,
                      "timing": "hipEvents on the launch stream around 4 rounds of the kernel's launches of one step (one per block), back to back"},
         "token_hbm_gbps": b_tok / (ms_per_step * 1e-3) / 1e9,

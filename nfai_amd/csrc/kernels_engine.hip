@@ -213,18 +213,11 @@ __device__ __forceinline__ void eng_loader(const EngineParams &p, uint8_t *lds, 
         const uint32_t KC = o.K >> 9, nu = ue - ub;
         for (uint32_t q0 = 0; q0 < nu && ok; q0 += ENG_NC) {
             const uint32_t nuq = min((uint32_t)ENG_NC, nu - q0);
-            const GLOBAL_AS uint8_t *rows[ENG_NC][2];
-#pragma unroll
-            for (int w = 0; w < ENG_NC; w++)
-#pragma unroll
-                for (int sub = 0; sub < 2; sub++) rows[w][sub] = eng_row(o, ub + q0 + min((uint32_t)w, nuq - 1), sub) + lane * 16;
-#pragma unroll
-            for (int sub = 0; sub < 2; sub++)
-                for (uint32_t c0 = 0; c0 < KC; c0 += 8) {
+            for (uint32_t sub = 0; sub < 2 && ok; sub++)
+                for (uint32_t c0 = 0; c0 < KC && ok; c0 += 8) {
                     const uint32_t n = min(8u, KC - c0);
-#pragma unroll
-                    for (int w = 0; w < ENG_NC; w++)
-                        if ((uint32_t)w < nuq) issue(rows[w][sub] + (uint64_t)c0 * 1024, n);
+                    for (uint32_t w = 0; w < nuq; w++)  // the row base is wave-uniform arithmetic: recomputed, not kept in an array
+                        issue(eng_row(o, ub + q0 + w, sub) + (uint64_t)c0 * 1024 + lane * 16, n);
                 }
         }
     }

@@ -1299,9 +1299,15 @@ NFAI_API int32_t nfai_hip_llama_profile_kernel(nfai_model_t h, uint32_t token, i
     // Infinity Cache, so nothing is re-read from cache), `reps` rounds, back to back between ONE pair of events.  Decode
     // launches are idempotent (outputs never alias inputs), so the replay leaves the model state as the step left it.
     hipStream_t s = m->ctx->stream;
+    // Engine launches hand vectors over under a per-token tag: a replay with the tag unchanged would find every hand-off already
+    // complete and never wait.  So each replayed engine launch is preceded by the one-block kernel that advances the tag (as in
+    // a real token), and the same number of those kernels alone is timed and subtracted.
+    const bool bump = cls == KC_ENGINE;
+    auto bump_launch = [&]() { return launch_token_begin(nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, m->d_pos, s, m->d_epoch); };
     HIP_TRY(hipEventRecord(m->prof_rep_ev[0], s));
     for (uint32_t r = 0; r < reps; r++)
         for (const Op &op : m->prof_ops) {
+            if (bump && bump_launch() != hipSuccess) return fail(NFAI_ERR_HIP, "profile_kernel: tag launch failed");
             hipError_t e = op.kind == 0 ? launch_gemv(op.g, s) : (op.kind == 1 ? launch_attn_decode(op.a, s) : op.f(s));
             if (e != hipSuccess) return fail(NFAI_ERR_HIP, "profile_kernel: replay launch failed: %s", hipGetErrorString(e));
         }
@@ -1309,6 +1315,16 @@ NFAI_API int32_t nfai_hip_llama_profile_kernel(nfai_model_t h, uint32_t token, i
     HIP_TRY(hipStreamSynchronize(s));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, m->prof_rep_ev[0], m->prof_rep_ev[1]));
+    if (bump) {
+        HIP_TRY(hipEventRecord(m->prof_rep_ev[0], s));
+        for (size_t i = 0; i < (size_t)reps * m->prof_ops.size(); i++)
+            if (bump_launch() != hipSuccess) return fail(NFAI_ERR_HIP, "profile_kernel: tag launch failed");
+        HIP_TRY(hipEventRecord(m->prof_rep_ev[1], s));
+        HIP_TRY(hipStreamSynchronize(s));
+        float ms0 = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms0, m->prof_rep_ev[0], m->prof_rep_ev[1]));
+        ms -= ms0;
+    }
     *us_avg = ms * 1e3f / (float)((size_t)reps * m->prof_ops.size());
     m->prof_ops.clear();
     return NFAI_OK;

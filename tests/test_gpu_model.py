@@ -412,8 +412,10 @@ def test_engine_two_full_width_blocks(mgr, dims):
 
 
 def test_engine_pipeline_stages_and_fallback(mgr):
-    """Layer ranges as stages with the engine on: bit-identical to the whole model with the engine on.  A model the engine
-    cannot take (K not a multiple of 512) silently runs the five-launch path."""
+    """Layer ranges as stages with the engine on against the whole model with the engine on: the first block of a stage gets
+    its q|k|v from the GEMV kernel instead of the previous block's engine launch (another summation tree), so the results agree
+    to the summation-order tolerance rather than bit for bit.  A model the engine cannot take (K not a multiple of 512)
+    silently runs the five-launch path."""
     from nfai_amd.hip import ShaderProperty
     from nfai_amd.llama_model import LlamaModel
     dims = synth.TINY_D128
@@ -427,7 +429,7 @@ def test_engine_pipeline_stages_and_fallback(mgr):
         want, am = whole.Step(t)
         s0.StageStep(t, None, h01.buffer.device_ptr)
         lg, am2 = s1.StageStep(0, h01.buffer.device_ptr, None, want_logits=True)
-        np.testing.assert_array_equal(lg, want)
+        np.testing.assert_allclose(lg, want, rtol=0, atol=1e-4)
         assert am == am2
     for m in (whole, s0, s1):
         m.Dispose()
