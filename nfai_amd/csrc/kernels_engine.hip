@@ -168,6 +168,8 @@ __device__ __forceinline__ void eng_loader(const EngineParams &p, uint8_t *lds, 
     uint32_t ps = 0, pgen = 0;  // slot / generation of sequence number `published`
     LDS_AS uint8_t *ring = (LDS_AS uint8_t *)(lds + p.ring_off);
     bool ok = true;
+    STAMP_DECL;
+    STAMP(0);  // loader: start | last piece of op 0..3 issued (1..4) | everything landed (5)
     // n consecutive pieces of one row, split where they cross a slot boundary
     auto issue = [&](const GLOBAL_AS uint8_t *src, uint32_t n) {
         while (n && ok) {
@@ -220,6 +222,9 @@ __device__ __forceinline__ void eng_loader(const EngineParams &p, uint8_t *lds, 
                         issue(eng_row(o, ub + q0 + w, sub) + (uint64_t)c0 * 1024 + lane * 16, n);
                 }
         }
+#ifdef NFAI_STAMPS
+        if (oi == 0) STAMP(1); else if (oi == 1) STAMP(2); else if (oi == 2) STAMP(3); else STAMP(4);
+#endif
     }
     // drain: everything issued has landed; publish the remaining slots (the last one may be partial)
     eng_wait_vmcnt<0>();
@@ -228,6 +233,8 @@ __device__ __forceinline__ void eng_loader(const EngineParams &p, uint8_t *lds, 
         lds_st(W_FULL + ps * 4, pgen + 1);
         if (++ps == nslot) { ps = 0; pgen++; }
     }
+    STAMP(5);
+    STAMP_FLUSH(p.stamps, blockIdx.x * ENG_WAVES, 6);
 }
 
 __device__ __forceinline__ void eng_publish(uint64_t *g, uint32_t idx, uint32_t epoch, float v)
@@ -252,6 +259,7 @@ __device__ __forceinline__ void eng_consumer(const EngineParams &p, uint8_t *lds
     };
     const uint32_t pos = p.pos ? ((const GLOBAL_AS uint32_t *)p.pos)[0] : 0u;
     bool ok = true;
+    STAMP_DECL;  // consumer: activation of op i seen (2i) | last unit of op i finished (2i + 1)
     for (uint32_t oi = 0; oi < p.n_ops && ok; oi++) {
         const EngOp &o = p.op[oi];
         uint32_t ub, ue;
@@ -261,6 +269,9 @@ __device__ __forceinline__ void eng_consumer(const EngineParams &p, uint8_t *lds
         release_below((gbase + (w < nu ? w * min(8u, KC) : nu * 2 * KC)) / ENG_SLOT);
         if (!lds_wait_ge(W_XREADY, oi + 1, p.err, 0x20u)) { ok = false; break; }
         const float *xs = reinterpret_cast<const float *>(lds + (o.x_sel ? p.xb_off : p.xa_off));
+#ifdef NFAI_STAMPS
+        if (oi == 0) STAMP(0); else if (oi == 1) STAMP(2); else if (oi == 2) STAMP(4); else STAMP(6);
+#endif
         for (uint32_t q0 = 0; q0 + w < nu && ok; q0 += ENG_NC) {
             const uint32_t nuq = min((uint32_t)ENG_NC, nu - q0), qbase = gbase + q0 * 2 * KC;
             const uint32_t u = ub + q0 + w;
@@ -337,9 +348,13 @@ __device__ __forceinline__ void eng_consumer(const EngineParams &p, uint8_t *lds
             }
         }
         gbase += nu * 2 * KC;
+#ifdef NFAI_STAMPS
+        if (oi == 0) STAMP(1); else if (oi == 1) STAMP(3); else if (oi == 2) STAMP(5); else STAMP(7);
+#endif
         if (lane == 0) lds_add(W_DONE, 1);  // this wave's outputs of the op are on their way
     }
     release_below((gbase + ENG_SLOT - 1) / ENG_SLOT);
+    STAMP_FLUSH(p.stamps, blockIdx.x * ENG_WAVES + 1 + w, 8);
 }
 
 // ---- control wave: gathers ------------------------------------------------------------------------------------------------
@@ -410,6 +425,8 @@ __device__ __forceinline__ void eng_control(const EngineParams &p, uint8_t *lds,
 {
     float *XA = reinterpret_cast<float *>(lds + p.xa_off), *XR = reinterpret_cast<float *>(lds + p.xr_off);
     float *XB = reinterpret_cast<float *>(lds + p.xb_off);
+    STAMP_DECL;  // control: start | x of op 0 set | local consumers done with op 0 | h gathered | done op 1 | act gathered | done op 2 | x gathered
+    STAMP(0);
     // op 0 (Wo + residual): attention output -> XB, block input -> XR; both are plain vectors of the previous launch
     for (uint32_t k = lane * 4; k < p.HD; k += 256)
         *reinterpret_cast<f32x4 *>(XB + eng_xs_index(k)) = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.att + k);
@@ -417,25 +434,33 @@ __device__ __forceinline__ void eng_control(const EngineParams &p, uint8_t *lds,
         *reinterpret_cast<f32x4 *>(XR + k) = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.x_in + k);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     lds_st(W_XREADY, 1);
+    STAMP(1);
     float ss;
     // edge h = x + Wo.att: every CU's rows -> XR (raw, the residual of Wdown) and XA = RMSNorm(h) * ffn_norm
     if (!lds_wait_ge(W_DONE, ENG_NC * 1, p.err, 0x100u)) return;
+    STAMP(2);
     if (!eng_gather<false>(p.g_h, p.E, epoch, XR, lane, p.err, ss)) return;
     eng_norm(XR, p.gamma_ffn, XA, p.E, ss, p.eps, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     lds_st(W_XREADY, 2);
+    STAMP(3);
     // edge act = up * silu(gate) -> XB
     if (!lds_wait_ge(W_DONE, ENG_NC * 2, p.err, 0x200u)) return;
+    STAMP(4);
     if (!eng_gather<true>(p.g_act, p.F, epoch, XB, lane, p.err, ss)) return;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     lds_st(W_XREADY, 3);
-    if (p.n_ops < 4) return;
+    STAMP(5);
+    if (p.n_ops < 4) { STAMP_FLUSH(p.stamps, blockIdx.x * ENG_WAVES + 1 + ENG_NC, 6); return; }
     // edge x' = h + Wdown.act -> XA = RMSNorm(x') * attn_norm of the next block
     if (!lds_wait_ge(W_DONE, ENG_NC * 3, p.err, 0x400u)) return;
+    STAMP(6);
     if (!eng_gather<false>(p.g_x, p.E, epoch, XR, lane, p.err, ss)) return;
     eng_norm(XR, p.gamma_next, XA, p.E, ss, p.eps, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     lds_st(W_XREADY, 4);
+    STAMP(7);
+    STAMP_FLUSH(p.stamps, blockIdx.x * ENG_WAVES + 1 + ENG_NC, 8);
 }
 
 template <int AHEAD>

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--model", default="llama-3.2-3b")
     ap.add_argument("--context", type=int, default=512)
     ap.add_argument("--tokens", type=int, default=6)
+    ap.add_argument("--engine", type=int, default=0, help="1: one engine launch per block (kernels_engine.hip), stamps per wave role")
     a = ap.parse_args()
     import torch
     import bench as B
@@ -59,7 +60,7 @@ def main():
     lib.nfai_hip_debug_stamps_install(C.c_void_p(buf.data_ptr()), n_slots)
     mgr = HipBufferManager(0)
     Cc = a.context + a.tokens + 2
-    m = LlamaModel(mgr, synth.make_metadata(dims), B.as_model_tensors(_lib, weights), Cc, dims=dict(
+    m = LlamaModel(mgr, synth.make_metadata(dims), B.as_model_tensors(_lib, weights), Cc, engine=bool(a.engine), dims=dict(
         E=dims.E, L=dims.L, H=dims.H, Hkv=dims.Hkv, D=dims.D, F=dims.F, V=dims.V, eps=1e-5, rope_dims=dims.D, rope_base=500000.0))
     m.SetToken(128000 % dims.V)
     m.Enqueue(a.context + a.tokens)   # the graph is captured at the first token: slots = launch order within a token
@@ -77,6 +78,32 @@ def main():
     # one token = the slots captured in the graph, in launch order
     per_cls = {}
     launches = []
+    eng = {"loader": [], "consumer": [], "control": []}
+    eng_span, eng_gap = [], []
+    for s, (name, grid, block) in enumerate(infos):
+        if name != "engine":
+            continue
+        t = st[s][: grid * 6].reshape(grid, 6, WORDS)
+        t0 = t[t > 0].min()
+        rel = np.where(t > 0, t - t0, np.nan)
+        eng["loader"].append(rel[:, 0, :6])
+        eng["consumer"].append(rel[:, 1:5, :].reshape(-1, 8))
+        eng["control"].append(rel[:, 5, :])
+        eng_span.append(float(np.nanmax(rel)))
+    if eng_span:
+        def med(rows, k):
+            a_ = np.concatenate(rows)[:, k]
+            a_ = a_[~np.isnan(a_)]
+            return pct(a_) if a_.size else None
+        names = {"loader": ["start", "op0 (Wo) issued", "op1 (gate|up) issued", "op2 (Wdown) issued", "op3 (next q|k|v) issued", "all landed"],
+                 "consumer": ["x of op0 seen", "op0 done", "x of op1 seen", "op1 done", "x of op2 seen", "op2 done", "x of op3 seen", "op3 done"],
+                 "control": ["start", "att/x in LDS", "local consumers done op0", "h gathered + normalised", "local done op1", "act gathered",
+                             "local done op2", "x' gathered + normalised"]}
+        print(json.dumps({"what": "engine launch (kernels_engine.hip): time of each event since the launch's first stamp, us, [median, p10, p90] "
+                                  "over the workgroups (x 4 consumer waves) of all blocks' launches in one token", "model": a.model,
+                          "launches": len(eng_span), "span_us": pct(eng_span),
+                          "roles": {r: {names[r][k]: med(v, k) for k in range(len(names[r]))} for r, v in eng.items()}}, indent=1))
+        return
     for s, (name, grid, block) in enumerate(infos):
         t = st[s]
         live = t[:, 0] > 0
