@@ -890,12 +890,18 @@ NFAI_API int32_t nfai_hip_engine_block(nfai_ctx_t h, nfai_buf_t Wo, nfai_buf_t W
     }
     // cos/sin table of the position (when q|k|v is on) and the epoch of this call's hand-offs
     LAUNCH_TRY(launch_token_begin(nullptr, 0, nullptr, nullptr, 0, fr, scratch_ropecs(c), nfreq, scratch_pos(c), c->stream, words));
-    hipError_t le = launch_engine(e, c->stream);
+    void *pdev = nullptr;
+    HIP_TRY(hipMalloc(&pdev, engine_params_bytes()));
+    EnginePlan plan;
+    hipError_t le = engine_plan(e, pdev, plan);
+    if (le == hipSuccess) le = launch_engine(plan, c->stream);
+    uint32_t err = 0;
+    if (le == hipSuccess) le = hipMemcpyAsync(&err, words + 1, 4, hipMemcpyDeviceToHost, c->stream);
+    hipError_t se = hipStreamSynchronize(c->stream);
+    hipFree(pdev);
     if (le == hipErrorInvalidValue) return fail(NFAI_ERR_INVALID, "engine_block: unsupported shape (E=%u F=%u HD=%u)", E, F, HD);
     if (le != hipSuccess) return fail(NFAI_ERR_HIP, "engine_block: launch failed: %s", hipGetErrorString(le));
-    uint32_t err = 0;
-    HIP_TRY(hipMemcpyAsync(&err, words + 1, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(se);
     if (err) return fail(NFAI_ERR_HIP, "engine_block: a bounded wait inside the launch gave up (code 0x%x)", err);
     return NFAI_OK;
 }

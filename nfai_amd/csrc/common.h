@@ -195,7 +195,14 @@ struct EngineArgs {
     uint32_t *err = nullptr;         // device word: non-zero after a bounded wait gave up
     uint32_t n_cu = 256;
 };
-hipError_t launch_engine(const EngineArgs &a, hipStream_t s);
+struct EnginePlan {  // a planned engine launch: its parameter block in device memory + the launch geometry
+    void *params_dev = nullptr;
+    uint32_t lds_bytes = 0, n_cu = 0;
+    int ahead = 0;
+};
+size_t engine_params_bytes();
+hipError_t engine_plan(const EngineArgs &a, void *params_dev, EnginePlan &plan);  // synchronous copy: outside stream capture
+hipError_t launch_engine(const EnginePlan &plan, hipStream_t s);
 
 // basic 1:1 ops
 hipError_t launch_embed(const void *table, int type, const uint32_t *tok, float *y, uint32_t E, hipStream_t s);

@@ -7,18 +7,20 @@
 // Inside one launch the weight stream never stops: a LOADER wave per CU runs ahead of every dependency through a ring of
 // 8-KiB LDS slots filled by LDS-DMA (global_load_lds_dwordx4, non-temporal: each byte is read once by one CU), CONSUMER waves
 // multiply what has landed, and the activation vector of the next projection travels between the CUs as 8-byte
-// {value, tag} granules written through to memory (one sc1 store each) that a CONTROL wave per CU sweeps with sc1 loads until
-// every tag carries this token's epoch — the data is the flag: no grid barrier, no counter, nothing to reset
-// (MI355X guide: rows ldsdma-fill, nt-weights, allgather, engine-vs-launches; Guideline 16, R2).
+// {value, tag} granules written through to memory (one sc1 store each) that the consumer waves sweep with sc1 loads — each its
+// share of the vector — until every tag carries this token's epoch: the data is the flag, no grid barrier, no counter, nothing
+// to reset (MI355X guide: rows ldsdma-fill, nt-weights, allgather, engine-vs-launches; Guideline 16, R2).
 //
-//   workgroup = 1 loader wave | 4 consumer waves | 1 control wave, one per CU, all co-resident (LDS: >= 120 KiB each)
+//   workgroup = 1 loader wave + ENG_NC consumer waves, one workgroup per CU, all co-resident (LDS: >= 120 KiB each)
 //   piece     = 1 KiB = 512 fp16 weights of one matrix row: one LDS-DMA wave-instruction, one ds_read_b128 per consumer lane
-//   unit      = two rows that finish together (rows 2u, 2u+1; gate row u + up row u; a RoPE pair) = 2*K/512 pieces, owned by
-//               ONE consumer wave, so a row is reduced inside a wave (DPP) and its epilogue needs nobody else
+//   unit      = two rows that finish together (rows 2u, 2u+1; gate row u + up row u; a RoPE pair), owned by ONE consumer wave:
+//               a row is reduced inside a wave (DPP), both rows share every activation read, the epilogue needs nobody else
 //   op        = one projection; the CU owns a contiguous range of its units; the pieces of all ops form ONE flat sequence
 //               through the ring, so the loader is already fetching the next projection while this one waits for its input
-//   slot      = 8 pieces; loader -> consumers: full_gen[slot] behind a counted vmcnt; consumers -> loader: a release mark per consumer
-//               after their reads are in registers (MI355X guide, ring-gemm: a FULL word per loader, a FREE word per consumer)
+//   slot      = 8 pieces; loader -> consumers: one monotonic count of landed slots (behind a counted vmcnt); consumers ->
+//               loader: a release mark per consumer wave (MI355X guide, ring-gemm: FULL / FREE words in LDS)
+//   edge      = between two ops: every consumer wave gathers its share of the granule vector, the waves of the CU meet at an
+//               LDS counter (sum of squares for the RMSNorm, then the normalised vector), and go on
 //
 // Numerics: the same fp16-weight x fp32-activation FMAs and fp32 epilogues as kernels_gemv.hip (RMSNorm as RMSNormShader.cs:
 // 136-149, SiLU as SiLUShader.cs:121-123, RoPE as RoPEShader.cs:249-262); only the summation tree differs.  Bit-reproducible:
@@ -36,11 +38,12 @@ namespace nfai {
 typedef uint64_t GLOBAL_AS gu64;
 
 constexpr int ENG_NC = 4;                   // consumer waves
-constexpr int ENG_WAVES = ENG_NC + 2;       // + loader + control
+constexpr int ENG_WAVES = ENG_NC + 1;       // + loader
 constexpr int ENG_THREADS = ENG_WAVES * 64;
 constexpr int ENG_SLOT = 8;                 // pieces per slot (8 KiB)
 constexpr int ENG_MAX_OPS = 4;
-constexpr uint32_t ENG_SPIN_CAP = 1u << 21; // x s_sleep(2): tens of milliseconds, then give up
+constexpr int ENG_GL = 16;                  // 16-byte loads per lane and gather chunk
+constexpr uint32_t ENG_SPIN_CAP = 1u << 21; // x s_sleep: tens of milliseconds, then give up
 
 enum { ENG_RESIDUAL = 0, ENG_GATEUP = 1, ENG_QKV = 2 };
 
@@ -79,41 +82,53 @@ struct EngineParams {
 };
 
 // ---- LDS words, accessed with inline asm: the waitcnt pass must not see them, or it would make the loader wait for its
-//      LDS-DMAs (pending LDS writes to the same array) before every flag access (MI355X guide, 5.7) -------------------------
+//      LDS-DMAs (pending LDS writes to the same array) before every flag access (MI355X guide, 5.7).  Every lane reads the
+//      same word, so the value (and every branch on it) is made wave-uniform. -----------------------------------------------
 __device__ __forceinline__ uint32_t lds_ld(uint32_t addr)
 {
     uint32_t v;
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
-    return __builtin_amdgcn_readfirstlane(v);  // every lane reads the same word: the value (and every branch on it) is wave-uniform
+    return __builtin_amdgcn_readfirstlane(v);
 }
 __device__ __forceinline__ void lds_st(uint32_t addr, uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 __device__ __forceinline__ void lds_add(uint32_t addr, uint32_t v) { asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
-
-constexpr uint32_t W_ABORT = 0, W_XREADY = 4, W_DONE = 8, W_REL = 16, W_FULL = 64;  // byte offsets of the control words
-// W_REL: one word per consumer wave (16-byte aligned block of ENG_NC words): slot sequence numbers [0, rel) are released by it.
-// W_FULL: one word per ring slot: generation (+1) whose pieces have landed.
-
-// the smallest of the four consumers' release marks (one ds_read_b128), wave-uniform
-__device__ __forceinline__ uint32_t lds_ld_min4(uint32_t addr)
+// the smallest of the consumers' release marks (ds_read_b128 per four of them)
+__device__ __forceinline__ uint32_t lds_ld_min_rel(uint32_t addr)
 {
-    u32x4 v;
-    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
-    const uint32_t a = min(min(v[0], v[1]), min(v[2], v[3]));
-    return __builtin_amdgcn_readfirstlane(a);
+    uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < ENG_NC; i += 4) {
+        u32x4 v;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr + i * 4) : "memory");
+        m = min(m, min(min(v[0], v[1]), min(v[2], v[3])));
+    }
+    return __builtin_amdgcn_readfirstlane(m);
 }
 
-// bounded wait until the LDS word at `addr` is >= target; false on abort / timeout
-__device__ __forceinline__ bool lds_wait_ge(uint32_t addr, uint32_t target, uint32_t *err, uint32_t code)
+// byte offsets of the control words (the first KiB of LDS)
+constexpr uint32_t W_ABORT = 0;     // non-zero: a wait gave up, everybody leaves
+constexpr uint32_t W_PUB = 4;       // loader: slot sequence numbers [0, pub) have landed
+constexpr uint32_t W_ARRIVE = 8;    // consumers' meeting counter (monotonic)
+constexpr uint32_t W_REL = 32;      // per consumer wave: slot sequence numbers [0, rel) will not be read by it again
+constexpr uint32_t W_SS = 128;      // per consumer wave: its share of the sum of squares of the vector being gathered
+static_assert(ENG_NC % 4 == 0 && ENG_NC <= 16, "release marks are read four at a time");
+
+__device__ __forceinline__ bool eng_give_up(uint32_t *err, uint32_t code)
+{
+    lds_st(W_ABORT, 1);
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_or(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
+
+// bounded wait until the LDS word at `addr` is >= target; returns the value seen (>= target), or ~0 on abort / timeout
+__device__ __forceinline__ bool lds_wait_ge(uint32_t addr, uint32_t target, uint32_t *err, uint32_t code, uint32_t &seen)
 {
     for (uint32_t spins = 0;; spins++) {
-        if ((int32_t)(lds_ld(addr) - target) >= 0) return true;
+        seen = lds_ld(addr);
+        if ((int32_t)(seen - target) >= 0) return true;
         if (lds_ld(W_ABORT) != 0) return false;
-        if (spins > ENG_SPIN_CAP) {
-            lds_st(W_ABORT, 1);
-            if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_or(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(2);
+        if (spins > ENG_SPIN_CAP) return eng_give_up(err, code);
+        __builtin_amdgcn_s_sleep(1);
     }
 }
 
@@ -153,38 +168,44 @@ __device__ __forceinline__ uint32_t eng_xs_index(uint32_t k)
 }
 
 // ---- loader wave: the flat piece sequence of all ops into the ring -------------------------------------------------------
-// Piece order inside an op: the CU's units are taken four at a time (a "quad": one unit per consumer wave); inside a quad the
-// rows advance together, eight pieces at a time: for sub-row 0/1, for each group of <= 8 chunks, for consumer 0..3.  So the four
-// consumers walk the ring side by side whatever the row length (a Wdown row of Llama-3.1-8B alone is 28 KiB).
-//   offset of (sub, c0, w) inside a quad of nuq units = (sub * KC + c0) * nuq + w * min(8, KC - c0)
+// Piece order inside an op: the CU's units are taken ENG_NC at a time (a "round": one unit per consumer wave); inside a round
+// the rows advance together, eight chunks at a time: for each group of <= 8 chunks, for consumer 0..NC-1: the group's pieces of
+// the unit's first row, then of its second row.  So the consumers walk the ring side by side whatever the row length (a Wdown
+// row of Llama-3.1-8B alone is 28 KiB), and a consumer finds the two rows of a chunk range next to each other.
+//   offset of (c0, w) inside a round of nur units = c0 * 2 * nur + w * 2 * n,  n = min(8, KC - c0); second row at + n
 template <int AHEAD>
 __device__ __forceinline__ void eng_loader(const EngineParams &p, uint8_t *lds, uint32_t lane)
 {
     const uint32_t nslot = p.nslot, ring_pieces = nslot * ENG_SLOT;
-    // position of the next piece (all wave-uniform): ring index rp, `within` pieces of the current slot issued
-    uint32_t rp = 0, within = 0;
-    uint32_t seq = 0;           // slot sequence number being filled
-    uint32_t published = 0;     // slot sequence numbers [0, published) are marked full
-    uint32_t ps = 0, pgen = 0;  // slot / generation of sequence number `published`
+    uint32_t rp = 0, within = 0;  // ring index of the next piece; pieces of the current slot already issued
+    uint32_t seq = 0;             // slot sequence number being filled
+    uint32_t published = 0;       // slot sequence numbers [0, published) have been declared landed
+    uint32_t min_rel = 0;         // last value seen of the consumers' smallest release mark
     LDS_AS uint8_t *ring = (LDS_AS uint8_t *)(lds + p.ring_off);
     bool ok = true;
     STAMP_DECL;
     STAMP(0);  // loader: start | last piece of op 0..3 issued (1..4) | everything landed (5)
+#ifdef NFAI_STAMPS
+    unsigned long long t_free = 0, t_mem = 0;  // ticks spent waiting for a free slot (consumers) / for loads to land (memory)
+#endif
     // n consecutive pieces of one row, split where they cross a slot boundary
     auto issue = [&](const GLOBAL_AS uint8_t *src, uint32_t n) {
         while (n && ok) {
-            if (within == 0 && seq >= nslot) {  // a new slot: every consumer must have released its previous occupant (seq - nslot)
-                const uint32_t need = seq - nslot + 1;
-                for (uint32_t spins = 0; (int32_t)(lds_ld_min4(W_REL) - need) < 0; spins++) {
+            if (within == 0 && seq >= nslot && (int32_t)(min_rel - (seq - nslot + 1)) < 0) {
+                // a new slot: every consumer must have released its previous occupant (sequence number seq - nslot)
+#ifdef NFAI_STAMPS
+                const unsigned long long ta = __builtin_amdgcn_s_memrealtime();
+#endif
+                for (uint32_t spins = 0;; spins++) {
+                    min_rel = lds_ld_min_rel(W_REL);
+                    if ((int32_t)(min_rel - (seq - nslot + 1)) >= 0) break;
                     if (lds_ld(W_ABORT) != 0) { ok = false; break; }
-                    if (spins > ENG_SPIN_CAP) {
-                        lds_st(W_ABORT, 1);
-                        if (lane == 0) __hip_atomic_fetch_or(p.err, 0x10u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = false;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
+                    if (spins > ENG_SPIN_CAP) { ok = eng_give_up(p.err, 0x10u); break; }
+                    __builtin_amdgcn_s_sleep(1);
                 }
+#ifdef NFAI_STAMPS
+                t_free += __builtin_amdgcn_s_memrealtime() - ta;
+#endif
                 if (!ok) break;
             }
             const uint32_t run = min(n, (uint32_t)ENG_SLOT - within);
@@ -199,10 +220,14 @@ __device__ __forceinline__ void eng_loader(const EngineParams &p, uint8_t *lds, 
                 within = 0;
                 if (rp == ring_pieces) rp = 0;
                 if (seq >= (uint32_t)AHEAD) {
+#ifdef NFAI_STAMPS
+                    const unsigned long long ta = __builtin_amdgcn_s_memrealtime();
+#endif
                     eng_wait_vmcnt<ENG_SLOT * AHEAD>();
-                    lds_st(W_FULL + ps * 4, pgen + 1);
-                    published++;
-                    if (++ps == nslot) { ps = 0; pgen++; }
+#ifdef NFAI_STAMPS
+                    t_mem += __builtin_amdgcn_s_memrealtime() - ta;
+#endif
+                    lds_st(W_PUB, ++published);
                 }
                 seq++;
             }
@@ -213,28 +238,29 @@ __device__ __forceinline__ void eng_loader(const EngineParams &p, uint8_t *lds, 
         uint32_t ub, ue;
         eng_unit_range(o.NU, ub, ue);
         const uint32_t KC = o.K >> 9, nu = ue - ub;
-        for (uint32_t q0 = 0; q0 < nu && ok; q0 += ENG_NC) {
-            const uint32_t nuq = min((uint32_t)ENG_NC, nu - q0);
-            for (uint32_t sub = 0; sub < 2 && ok; sub++)
-                for (uint32_t c0 = 0; c0 < KC && ok; c0 += 8) {
-                    const uint32_t n = min(8u, KC - c0);
-                    for (uint32_t w = 0; w < nuq; w++)  // the row base is wave-uniform arithmetic: recomputed, not kept in an array
-                        issue(eng_row(o, ub + q0 + w, sub) + (uint64_t)c0 * 1024 + lane * 16, n);
+        for (uint32_t r0 = 0; r0 < nu && ok; r0 += ENG_NC) {
+            const uint32_t nur = min((uint32_t)ENG_NC, nu - r0);
+            for (uint32_t c0 = 0; c0 < KC && ok; c0 += 8) {
+                const uint32_t n = min(8u, KC - c0);
+                for (uint32_t w = 0; w < nur; w++) {  // the row bases are wave-uniform arithmetic: recomputed, not kept in an array
+                    issue(eng_row(o, ub + r0 + w, 0) + (uint64_t)c0 * 1024 + lane * 16, n);
+                    issue(eng_row(o, ub + r0 + w, 1) + (uint64_t)c0 * 1024 + lane * 16, n);
                 }
+            }
         }
 #ifdef NFAI_STAMPS
         if (oi == 0) STAMP(1); else if (oi == 1) STAMP(2); else if (oi == 2) STAMP(3); else STAMP(4);
 #endif
     }
-    // drain: everything issued has landed; publish the remaining slots (the last one may be partial)
+    // drain: everything issued has landed; the last slot may be partial
     eng_wait_vmcnt<0>();
-    const uint32_t total = seq + (within ? 1u : 0u);
-    for (; published < total; published++) {
-        lds_st(W_FULL + ps * 4, pgen + 1);
-        if (++ps == nslot) { ps = 0; pgen++; }
-    }
+    lds_st(W_PUB, seq + (within ? 1u : 0u));
+#ifdef NFAI_STAMPS
     STAMP(5);
-    STAMP_FLUSH(p.stamps, blockIdx.x * ENG_WAVES, 6);
+    _st.t[6] = t_free;
+    _st.t[7] = t_mem;
+    STAMP_FLUSH(p.stamps, blockIdx.x * ENG_WAVES, 8);
+#endif
 }
 
 __device__ __forceinline__ void eng_publish(uint64_t *g, uint32_t idx, uint32_t epoch, float v)
@@ -243,38 +269,197 @@ __device__ __forceinline__ void eng_publish(uint64_t *g, uint32_t idx, uint32_t 
                        __HIP_MEMORY_SCOPE_AGENT);  // one global_store_dwordx2 sc1: written through, value and tag together
 }
 
-// ---- consumer wave w: its units of every op ---------------------------------------------------------------------------
-__device__ __forceinline__ void eng_consumer(const EngineParams &p, uint8_t *lds, uint32_t w, uint32_t lane, uint32_t epoch)
-{
-    const uint32_t nslot = p.nslot, ring_pieces = nslot * ENG_SLOT;
-    const uint8_t *ring = lds + p.ring_off;
-    const float *XR = reinterpret_cast<const float *>(lds + p.xr_off);
-    uint32_t rel = 0;     // slot sequence numbers [0, rel) released by this wave
-    uint32_t gbase = 0;   // first piece of the current op
-    auto release_below = [&](uint32_t S) {  // this wave will not read slot sequence numbers < S again
+// ---- consumer waves ---------------------------------------------------------------------------------------------------
+struct EngCons {  // per-wave state (all wave-uniform)
+    uint32_t w, lane, nslot, ring_pieces;
+    uint32_t rel = 0;      // slot sequence numbers [0, rel) released
+    uint32_t pub = 0;      // last value seen of the loader's landed count
+    uint32_t g_prev = 0, rp_prev = 0;  // a piece index whose ring position is known
+    uint32_t meets = 0;    // meetings of the CU's consumer waves so far
+    uint32_t *err;
+    __device__ __forceinline__ void release_below(uint32_t S)
+    {
         if (S > rel) {
             rel = S;
             lds_st(W_REL + w * 4, rel);
         }
-    };
+    }
+    __device__ __forceinline__ uint32_t ring_pos(uint32_t g)  // g >= g_prev
+    {
+        uint32_t rp = rp_prev + (g - g_prev);
+        while (rp >= ring_pieces) rp -= ring_pieces;
+        g_prev = g;
+        rp_prev = rp;
+        return rp;
+    }
+    __device__ __forceinline__ bool wait_landed(uint32_t glast)
+    {
+        const uint32_t S = glast / ENG_SLOT;
+        if ((int32_t)(pub - (S + 1)) >= 0) return true;
+        return lds_wait_ge(W_PUB, S + 1, err, 0x40u, pub);
+    }
+    // all consumer waves of the CU have reached this point (their LDS writes before it are visible after it)
+    __device__ __forceinline__ bool meet()
+    {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) lds_add(W_ARRIVE, 1);
+        uint32_t seen;
+        return lds_wait_ge(W_ARRIVE, ENG_NC * ++meets, err, 0x20u, seen);
+    }
+};
+
+// One group of N chunks (c0 .. c0+N-1) of a unit: the two rows share every activation read.  Reads are batched four chunks
+// at a time (16 LDS reads in flight, 64 VGPRs).
+template <int N>
+__device__ __forceinline__ void eng_group(const uint8_t *ring, uint32_t rp, uint32_t ring_pieces, const float *xs, uint32_t c0, uint32_t lane,
+                                          float &a0, float &a1)
+{
+#pragma unroll
+    for (int b = 0; b < N; b += 4) {
+        constexpr int BMAX = 4;
+        const int nb = N - b < BMAX ? N - b : BMAX;
+        u32x4 w0[BMAX], w1[BMAX];
+        f32x4 x0[BMAX], x1[BMAX];
+#pragma unroll
+        for (int j = 0; j < BMAX; j++) {
+            if (j < nb) {
+                uint32_t r0 = rp + b + j, r1 = rp + N + b + j;
+                r0 = r0 >= ring_pieces ? r0 - ring_pieces : r0;
+                r1 = r1 >= ring_pieces ? r1 - ring_pieces : r1;
+                w0[j] = *reinterpret_cast<const u32x4 *>(ring + r0 * 1024 + lane * 16);
+                w1[j] = *reinterpret_cast<const u32x4 *>(ring + r1 * 1024 + lane * 16);
+                x0[j] = *reinterpret_cast<const f32x4 *>(xs + ((c0 + b + j) << 9) + (lane << 2));
+                x1[j] = *reinterpret_cast<const f32x4 *>(xs + ((c0 + b + j) << 9) + 256 + (lane << 2));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BMAX; j++) {
+            if (j < nb) {
+                a0 = dot8_f16(w0[j], x0[j], x1[j], a0);
+                a1 = dot8_f16(w1[j], x0[j], x1[j], a1);
+            }
+        }
+    }
+}
+
+// Gather this wave's share of an n-granule vector (n % (128 * ENG_NC) == 0): 16-byte sc1 loads (two granules per lane; L1 is
+// bypassed, so every pass reads what has reached memory), load index L = j * ENG_NC + w, swept until every tag == epoch.
+// MODE 0: raw values -> XR (linear) and the wave's sum of squares -> W_SS[w] (RMSNorm edges)   MODE 1: values -> dst permuted
+template <int MODE>
+__device__ __forceinline__ bool eng_gather(EngCons &c, const uint64_t *g, uint32_t n, uint32_t epoch, float *dst)
+{
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)g, 0, (int)(n * 8), 0x00020000);
+    float ss = 0.f;
+    const uint32_t nloads = n / (128 * ENG_NC);  // per lane of this wave
+    for (uint32_t l0 = 0; l0 < nloads; l0 += ENG_GL) {
+        const uint32_t nl = min((uint32_t)ENG_GL, nloads - l0);
+        u32x4 v[ENG_GL];
+        for (uint32_t spins = 0;; spins++) {
+            bool okc = true;
+#pragma unroll
+            for (int k = 0; k < ENG_GL; k++) {
+                const uint32_t L = (l0 + min((uint32_t)k, nl - 1)) * ENG_NC + c.w;
+                v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((L * 64 + c.lane) * 16), 0, 16));
+            }
+#pragma unroll
+            for (int k = 0; k < ENG_GL; k++) okc = okc && v[k][1] == epoch && v[k][3] == epoch;
+            if (__all(okc)) break;
+            if (lds_ld(W_ABORT) != 0) return false;
+            if (spins > (ENG_SPIN_CAP >> 5)) return eng_give_up(c.err, 0x80u);  // a pass is a memory round trip
+            __builtin_amdgcn_s_sleep(4);
+        }
+#pragma unroll
+        for (int k = 0; k < ENG_GL; k++) {
+            if ((uint32_t)k < nl) {
+                const uint32_t e = (((l0 + k) * ENG_NC + c.w) * 64 + c.lane) * 2;  // element index of the first of the two granules
+                const f32x4 vf = __builtin_bit_cast(f32x4, v[k]);  // whole-vector cast (on an ELEMENT lvalue hipcc 7.2 reads element 0)
+                const float a = vf[0], b = vf[2];
+                ss = fmaf(a, a, ss);
+                ss = fmaf(b, b, ss);
+                const uint32_t i = MODE == 1 ? eng_xs_index(e) : e;  // e is even: the pair stays adjacent under the permutation
+                *reinterpret_cast<f32x2 *>(dst + i) = f32x2{a, b};
+            }
+        }
+    }
+    if (MODE == 0) {
+        ss = wave_sum(ss);
+        lds_st(W_SS + c.w * 4, __builtin_bit_cast(uint32_t, ss));
+    }
+    return true;
+}
+
+// After the meeting that follows eng_gather<0>: XA[perm(k)] = (XR[k] / rms) * gamma[k] for this wave's share (RMSNormShader.cs:136-149).
+// gm[] = the wave's gains, loaded at kernel start (same (j, lane) -> element mapping as the gather).
+template <int NG>
+__device__ __forceinline__ void eng_norm(const EngCons &c, const float *XR, const f32x2 (&gm)[NG], float *XA, uint32_t E, float eps)
+{
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < ENG_NC; i++) tot += __builtin_bit_cast(float, lds_ld(W_SS + i * 4));  // fixed order: every wave, every CU, the same sum
+    const float rms = sqrtf(tot / (float)E + eps);
+    const uint32_t nloads = E / (128 * ENG_NC);
+#pragma unroll
+    for (int j = 0; j < NG; j++) {
+        if ((uint32_t)j < nloads) {
+            const uint32_t e = ((j * ENG_NC + c.w) * 64 + c.lane) * 2;
+            const f32x2 v = *reinterpret_cast<const f32x2 *>(XR + e);
+            f32x2 o;
+            o[0] = (v[0] / rms) * gm[j][0];
+            o[1] = (v[1] / rms) * gm[j][1];
+            *reinterpret_cast<f32x2 *>(XA + eng_xs_index(e)) = o;
+        }
+    }
+}
+
+constexpr int ENG_NGAMMA = 8;   // gains per lane and wave: E <= 128 * ENG_NC * ENG_NGAMMA (4096 at four consumer waves)
+
+__device__ __forceinline__ void eng_consumer(const EngineParams &p, uint8_t *lds, uint32_t w, uint32_t lane, uint32_t epoch)
+{
+    EngCons c;
+    c.w = w; c.lane = lane; c.nslot = p.nslot; c.ring_pieces = p.nslot * ENG_SLOT; c.err = p.err;
+    const uint8_t *ring = lds + p.ring_off;
+    float *XA = reinterpret_cast<float *>(lds + p.xa_off), *XR = reinterpret_cast<float *>(lds + p.xr_off);
+    float *XB = reinterpret_cast<float *>(lds + p.xb_off);
+    STAMP_DECL;  // consumer: activation of op i in LDS (2i) | this wave's last unit of op i finished (2i + 1)
+    // ---- requests first: this wave's share of the attention output and of the block input (plain vectors of the previous
+    //      launch), its RMSNorm gains for both edges, the position ---------------------------------------------------------
+    constexpr int NV = 4;  // float4 per lane of a plain vector: covers 4 * 64 * ENG_NC * NV elements (4096 at four consumer waves)
+    f32x4 av[NV], xv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const uint32_t k = ((i * ENG_NC + w) * 64 + lane) * 4;
+        av[i] = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.att + min(k, p.HD - 4));
+        xv[i] = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.x_in + min(k, p.E - 4));
+    }
+    f32x2 g1[ENG_NGAMMA], g2[ENG_NGAMMA];
+    const uint32_t ngam = p.E / (128 * ENG_NC);
+#pragma unroll
+    for (int j = 0; j < ENG_NGAMMA; j++) {
+        const uint32_t e = ((min((uint32_t)j, ngam - 1) * ENG_NC + w) * 64 + lane) * 2;
+        g1[j] = *reinterpret_cast<const GLOBAL_AS f32x2 *>((const GLOBAL_AS float *)p.gamma_ffn + e);
+        g2[j] = p.gamma_next ? *reinterpret_cast<const GLOBAL_AS f32x2 *>((const GLOBAL_AS float *)p.gamma_next + e) : f32x2{0.f, 0.f};
+    }
     const uint32_t pos = p.pos ? ((const GLOBAL_AS uint32_t *)p.pos)[0] : 0u;
-    bool ok = true;
-    STAMP_DECL;  // consumer: activation of op i seen (2i) | last unit of op i finished (2i + 1)
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const uint32_t k = ((i * ENG_NC + w) * 64 + lane) * 4;
+        if (k < p.HD) *reinterpret_cast<f32x4 *>(XB + eng_xs_index(k)) = av[i];
+        if (k < p.E) *reinterpret_cast<f32x4 *>(XR + k) = xv[i];
+    }
+    bool ok = c.meet();
+    uint32_t gbase = 0;   // first piece of the current op
     for (uint32_t oi = 0; oi < p.n_ops && ok; oi++) {
         const EngOp &o = p.op[oi];
         uint32_t ub, ue;
         eng_unit_range(o.NU, ub, ue);
         const uint32_t KC = o.K >> 9, nu = ue - ub;
-        // nothing before this wave's first piece of the op will be read by it again
-        release_below((gbase + (w < nu ? w * min(8u, KC) : nu * 2 * KC)) / ENG_SLOT);
-        if (!lds_wait_ge(W_XREADY, oi + 1, p.err, 0x20u)) { ok = false; break; }
-        const float *xs = reinterpret_cast<const float *>(lds + (o.x_sel ? p.xb_off : p.xa_off));
+        const float *xs = o.x_sel ? XB : XA;
 #ifdef NFAI_STAMPS
         if (oi == 0) STAMP(0); else if (oi == 1) STAMP(2); else if (oi == 2) STAMP(4); else STAMP(6);
 #endif
-        for (uint32_t q0 = 0; q0 + w < nu && ok; q0 += ENG_NC) {
-            const uint32_t nuq = min((uint32_t)ENG_NC, nu - q0), qbase = gbase + q0 * 2 * KC;
-            const uint32_t u = ub + q0 + w;
+        for (uint32_t r0 = 0; r0 + w < nu && ok; r0 += ENG_NC) {
+            const uint32_t nur = min((uint32_t)ENG_NC, nu - r0), rbase = gbase + r0 * 2 * KC;
+            const uint32_t u = ub + r0 + w;
             // what the epilogue reads from memory is requested now (RoPE pair)
             float cs0 = 1.f, cs1 = 0.f;
             uint32_t seg = 0, r = 0;
@@ -287,32 +472,27 @@ __device__ __forceinline__ void eng_consumer(const EngineParams &p, uint8_t *lds
                 cs0 = cs[0];
                 cs1 = cs[1];
             }
-            float acc[2] = {0.f, 0.f};
-#pragma unroll
-            for (int sub = 0; sub < 2; sub++) {
-                float a = 0.f;
-                for (uint32_t c0 = 0; c0 < KC && ok; c0 += 8) {
-                    const uint32_t n = min(8u, KC - c0);
-                    const uint32_t gfirst = qbase + ((uint32_t)sub * KC + c0) * nuq + w * n, glast = gfirst + n - 1;
-                    release_below(gfirst / ENG_SLOT);
-                    const uint32_t S = glast / ENG_SLOT, Sgen = S / nslot;
-                    if (!lds_wait_ge(W_FULL + (S - Sgen * nslot) * 4, Sgen + 1, p.err, 0x40u)) { ok = false; break; }
-                    const uint32_t rp0 = gfirst % ring_pieces;
-#pragma unroll 4
-                    for (uint32_t j = 0; j < n; j++) {
-                        const uint32_t c = c0 + j;
-                        uint32_t rp = rp0 + j;
-                        rp = rp >= ring_pieces ? rp - ring_pieces : rp;
-                        const u32x4 wv = *reinterpret_cast<const u32x4 *>(ring + rp * 1024 + lane * 16);
-                        const f32x4 x0 = *reinterpret_cast<const f32x4 *>(xs + (c << 9) + (lane << 2));
-                        const f32x4 x1 = *reinterpret_cast<const f32x4 *>(xs + (c << 9) + 256 + (lane << 2));
-                        a = dot8_f16(wv, x0, x1, a);
-                    }
+            float a0 = 0.f, a1 = 0.f;
+            for (uint32_t c0 = 0; c0 < KC && ok; c0 += 8) {
+                const uint32_t n = min(8u, KC - c0);
+                const uint32_t gfirst = rbase + c0 * 2 * nur + w * 2 * n;
+                c.release_below(gfirst / ENG_SLOT);
+                if (!c.wait_landed(gfirst + 2 * n - 1)) { ok = false; break; }
+                const uint32_t rp = c.ring_pos(gfirst);
+                switch (n) {
+                    case 8: eng_group<8>(ring, rp, c.ring_pieces, xs, c0, lane, a0, a1); break;
+                    case 7: eng_group<7>(ring, rp, c.ring_pieces, xs, c0, lane, a0, a1); break;
+                    case 6: eng_group<6>(ring, rp, c.ring_pieces, xs, c0, lane, a0, a1); break;
+                    case 5: eng_group<5>(ring, rp, c.ring_pieces, xs, c0, lane, a0, a1); break;
+                    case 4: eng_group<4>(ring, rp, c.ring_pieces, xs, c0, lane, a0, a1); break;
+                    case 3: eng_group<3>(ring, rp, c.ring_pieces, xs, c0, lane, a0, a1); break;
+                    case 2: eng_group<2>(ring, rp, c.ring_pieces, xs, c0, lane, a0, a1); break;
+                    default: eng_group<1>(ring, rp, c.ring_pieces, xs, c0, lane, a0, a1); break;
                 }
-                acc[sub] = a;
             }
             if (!ok) break;
-            const float a0 = wave_sum(acc[0]), a1 = wave_sum(acc[1]);
+            a0 = wave_sum(a0);
+            a1 = wave_sum(a1);
             if (lane == 0) {
                 if (o.mode == ENG_RESIDUAL) {
                     // host residual add of TransformerBlock.cs:153-158 / 176-180: input + projection
@@ -347,125 +527,44 @@ __device__ __forceinline__ void eng_consumer(const EngineParams &p, uint8_t *lds
                 }
             }
         }
+        if (!ok) break;
         gbase += nu * 2 * KC;
 #ifdef NFAI_STAMPS
         if (oi == 0) STAMP(1); else if (oi == 1) STAMP(3); else if (oi == 2) STAMP(5); else STAMP(7);
 #endif
-        if (lane == 0) lds_add(W_DONE, 1);  // this wave's outputs of the op are on their way
+        // nothing before this wave's first piece of the next op will be read by it again: the loader may run on while
+        // this wave gathers
+        if (oi + 1 < p.n_ops) {
+            const EngOp &nx = p.op[oi + 1];
+            uint32_t nb, ne;
+            eng_unit_range(nx.NU, nb, ne);
+            const uint32_t nKC = nx.K >> 9, nnu = ne - nb;
+            c.release_below((gbase + (w < nnu ? w * 2 * min(8u, nKC) : nnu * 2 * nKC)) / ENG_SLOT);
+        } else {
+            c.release_below((gbase + ENG_SLOT - 1) / ENG_SLOT);
+            break;
+        }
+        // ---- edge: the next op's activation vector from every CU ------------------------------------------------------------
+        if (oi == 0) {         // h = x + Wo.att -> XR (raw: the residual of Wdown), XA = RMSNorm(h) * ffn_norm
+            ok = eng_gather<0>(c, p.g_h, p.E, epoch, XR) && c.meet();
+            if (ok) { eng_norm<ENG_NGAMMA>(c, XR, g1, XA, p.E, p.eps); ok = c.meet(); }
+        } else if (oi == 1) {  // act = up * silu(gate) -> XB
+            ok = eng_gather<1>(c, p.g_act, p.F, epoch, XB) && c.meet();
+        } else {               // x' = h + Wdown.act -> XA = RMSNorm(x') * attn_norm of the next block
+            ok = eng_gather<0>(c, p.g_x, p.E, epoch, XR) && c.meet();
+            if (ok) { eng_norm<ENG_NGAMMA>(c, XR, g2, XA, p.E, p.eps); ok = c.meet(); }
+        }
     }
-    release_below((gbase + ENG_SLOT - 1) / ENG_SLOT);
     STAMP_FLUSH(p.stamps, blockIdx.x * ENG_WAVES + 1 + w, 8);
 }
 
-// ---- control wave: gathers ------------------------------------------------------------------------------------------------
-// Sweep n granules (n % 128 == 0) at g[] until every tag == epoch; values -> dst[index(k)] in LDS.  Returns the sum of squares.
-template <bool PERMUTE>
-__device__ __forceinline__ bool eng_gather(const uint64_t *g, uint32_t n, uint32_t epoch, float *dst, uint32_t lane, uint32_t *err,
-                                           float &ss_out)
-{
-    // 16-byte sc1 loads (two granules per lane): L1 is bypassed, every pass reads what has reached memory
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)g, 0, (int)(n * 8), 0x00020000);
-    float ss = 0.f;
-    const uint32_t nloads = n / 128;  // per lane
-    for (uint32_t l0 = 0; l0 < nloads; l0 += 8) {
-        const uint32_t nl = min(8u, nloads - l0);
-        u32x4 v[8];
-        for (uint32_t spins = 0;; spins++) {
-            bool okc = true;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const uint32_t li = l0 + min((uint32_t)k, nl - 1);
-                v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((li * 64 + lane) * 16), 0, 16));
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++) okc = okc && v[k][1] == epoch && v[k][3] == epoch;
-            if (__all(okc)) break;
-            if (lds_ld(W_ABORT) != 0) return false;
-            if (spins > (ENG_SPIN_CAP >> 5)) {  // a pass is a memory round trip (~2 us): the same tens of milliseconds
-                lds_st(W_ABORT, 1);
-                if (lane == 0) __hip_atomic_fetch_or(err, 0x80u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if ((uint32_t)k < nl) {
-                const uint32_t e = ((l0 + k) * 64 + lane) * 2;  // element index of the first of the two granules
-                const f32x4 vf = __builtin_bit_cast(f32x4, v[k]);  // whole-vector cast (on an ELEMENT lvalue hipcc 7.2 reads element 0)
-                const float a = vf[0], b = vf[2];
-                ss = fmaf(a, a, ss);
-                ss = fmaf(b, b, ss);
-                const uint32_t i = PERMUTE ? eng_xs_index(e) : e;  // e is even: the pair stays adjacent under the permutation
-                *reinterpret_cast<f32x2 *>(dst + i) = f32x2{a, b};
-            }
-        }
-    }
-    ss_out = ss;
-    return true;
-}
-
-// XA[perm(k)] = (XR[k] / rms) * gamma[k]   (RMSNormShader.cs:136-149)
-__device__ __forceinline__ void eng_norm(const float *XR, const float *gamma, float *XA, uint32_t E, float ss, float eps, uint32_t lane)
-{
-    const float rms = sqrtf(wave_sum(ss) / (float)E + eps);
-    for (uint32_t k = lane * 4; k < E; k += 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(XR + k);
-        const f32x4 gm = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)gamma + k);
-        f32x4 o;
-        o[0] = (v[0] / rms) * gm[0];
-        o[1] = (v[1] / rms) * gm[1];
-        o[2] = (v[2] / rms) * gm[2];
-        o[3] = (v[3] / rms) * gm[3];
-        *reinterpret_cast<f32x4 *>(XA + eng_xs_index(k)) = o;
-    }
-}
-
-__device__ __forceinline__ void eng_control(const EngineParams &p, uint8_t *lds, uint32_t lane, uint32_t epoch)
-{
-    float *XA = reinterpret_cast<float *>(lds + p.xa_off), *XR = reinterpret_cast<float *>(lds + p.xr_off);
-    float *XB = reinterpret_cast<float *>(lds + p.xb_off);
-    STAMP_DECL;  // control: start | x of op 0 set | local consumers done with op 0 | h gathered | done op 1 | act gathered | done op 2 | x gathered
-    STAMP(0);
-    // op 0 (Wo + residual): attention output -> XB, block input -> XR; both are plain vectors of the previous launch
-    for (uint32_t k = lane * 4; k < p.HD; k += 256)
-        *reinterpret_cast<f32x4 *>(XB + eng_xs_index(k)) = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.att + k);
-    for (uint32_t k = lane * 4; k < p.E; k += 256)
-        *reinterpret_cast<f32x4 *>(XR + k) = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.x_in + k);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    lds_st(W_XREADY, 1);
-    STAMP(1);
-    float ss;
-    // edge h = x + Wo.att: every CU's rows -> XR (raw, the residual of Wdown) and XA = RMSNorm(h) * ffn_norm
-    if (!lds_wait_ge(W_DONE, ENG_NC * 1, p.err, 0x100u)) return;
-    STAMP(2);
-    if (!eng_gather<false>(p.g_h, p.E, epoch, XR, lane, p.err, ss)) return;
-    eng_norm(XR, p.gamma_ffn, XA, p.E, ss, p.eps, lane);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    lds_st(W_XREADY, 2);
-    STAMP(3);
-    // edge act = up * silu(gate) -> XB
-    if (!lds_wait_ge(W_DONE, ENG_NC * 2, p.err, 0x200u)) return;
-    STAMP(4);
-    if (!eng_gather<true>(p.g_act, p.F, epoch, XB, lane, p.err, ss)) return;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    lds_st(W_XREADY, 3);
-    STAMP(5);
-    if (p.n_ops < 4) { STAMP_FLUSH(p.stamps, blockIdx.x * ENG_WAVES + 1 + ENG_NC, 6); return; }
-    // edge x' = h + Wdown.act -> XA = RMSNorm(x') * attn_norm of the next block
-    if (!lds_wait_ge(W_DONE, ENG_NC * 3, p.err, 0x400u)) return;
-    STAMP(6);
-    if (!eng_gather<false>(p.g_x, p.E, epoch, XR, lane, p.err, ss)) return;
-    eng_norm(XR, p.gamma_next, XA, p.E, ss, p.eps, lane);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    lds_st(W_XREADY, 4);
-    STAMP(7);
-    STAMP_FLUSH(p.stamps, blockIdx.x * ENG_WAVES + 1 + ENG_NC, 8);
-}
-
+// The parameters live in device memory (written once when the launch is planned): op i is picked with a run-time index, and a
+// run-time index into a by-value kernel argument would make hipcc copy the whole argument block to scratch (scratch accesses
+// count on vmcnt, which the loader counts by hand).
 template <int AHEAD>
-__global__ __launch_bounds__(ENG_THREADS) void k_engine(const EngineParams p)
+__global__ __launch_bounds__(ENG_THREADS) void k_engine(const EngineParams *__restrict__ pp)
 {
+    const EngineParams &p = *pp;
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -476,19 +575,20 @@ __global__ __launch_bounds__(ENG_THREADS) void k_engine(const EngineParams p)
     __syncthreads();
     const uint32_t epoch = ((const GLOBAL_AS uint32_t *)p.epoch)[0];
     if (wave == 0) eng_loader<AHEAD>(p, lds, lane);
-    else if (wave <= ENG_NC) eng_consumer(p, lds, wave - 1, lane, epoch);
-    else eng_control(p, lds, lane, epoch);
+    else eng_consumer(p, lds, wave - 1, lane, epoch);
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
-struct EngineArgs;  // common.h
+size_t engine_params_bytes() { return (sizeof(EngineParams) + 255) & ~(size_t)255; }
 
-hipError_t launch_engine(const EngineArgs &a, hipStream_t s)
+// Fill the launch's parameter block and copy it to `params_dev` (synchronous: call it outside stream capture, once per block).
+hipError_t engine_plan(const EngineArgs &a, void *params_dev, EnginePlan &plan)
 {
     EngineParams p{};
-    if (a.n_ops < 3 || a.n_ops > 4) return hipErrorInvalidValue;
+    if (a.n_ops < 3 || a.n_ops > 4 || !params_dev) return hipErrorInvalidValue;
     const uint32_t E = a.E, F = a.F, HD = a.HD;
-    if (E % 512 || F % 512 || HD % 512 || E % 128 || F % 128) return hipErrorInvalidValue;
+    if (E % 512 || F % 512 || HD % 512 || E % (128 * ENG_NC) || F % (128 * ENG_NC)) return hipErrorInvalidValue;
+    if (E > 128 * ENG_NC * ENG_NGAMMA || E > 4 * 64 * ENG_NC * 4 || HD > 4 * 64 * ENG_NC * 4) return hipErrorInvalidValue;  // per-lane register shares
     p.n_ops = a.n_ops;
     p.E = E; p.F = F; p.HD = HD;
     // op 0: Wo + residual
@@ -527,24 +627,33 @@ hipError_t launch_engine(const EngineArgs &a, hipStream_t s)
     static const int env_slots = getenv("NFAI_ENGINE_SLOTS") ? atoi(getenv("NFAI_ENGINE_SLOTS")) : 0;
     if (env_slots >= 5 && (uint32_t)env_slots <= nslot) nslot = (uint32_t)env_slots;
     p.nslot = nslot;
-    const uint32_t lds_bytes = p.ring_off + nslot * ENG_SLOT * 1024;
+    plan.lds_bytes = p.ring_off + nslot * ENG_SLOT * 1024;
     // slots of loads kept in flight (x 8 KiB): the ring keeps >= 3 slots beyond them (being read / waiting / being released)
-    int ahead = nslot >= 9 ? 6 : (nslot >= 7 ? 4 : 2);
+    int ahead = nslot >= 8 ? 4 : 2;  // measured: 2, 4 and 6 slots in flight stream at the same rate; 4 leaves the ring more room
     static const int env_ahead = getenv("NFAI_ENGINE_AHEAD") ? atoi(getenv("NFAI_ENGINE_AHEAD")) : 0;
     if ((env_ahead == 2 || env_ahead == 4 || env_ahead == 6) && (uint32_t)env_ahead + 3 <= nslot) ahead = env_ahead;
+    plan.ahead = ahead;
+    plan.n_cu = a.n_cu;
+    plan.params_dev = params_dev;
     NFAI_STAMP_SET(p, "engine", a.n_cu, ENG_THREADS);
+    return hipMemcpy(params_dev, &p, sizeof(p), hipMemcpyHostToDevice);
+}
+
+hipError_t launch_engine(const EnginePlan &plan, hipStream_t s)
+{
+    if (!plan.params_dev) return hipErrorInvalidValue;
     auto launch = [&](auto kern) -> hipError_t {
-        static bool attr_set[8] = {false, false, false, false, false, false, false, false};
-        if (!attr_set[ahead]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
+        static bool attr_set = false;  // one per instantiation of the lambda body = per kernel
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
-            attr_set[ahead] = true;
+            attr_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3(a.n_cu), dim3(ENG_THREADS), lds_bytes, s, p);
+        hipLaunchKernelGGL(kern, dim3(plan.n_cu), dim3(ENG_THREADS), plan.lds_bytes, s, static_cast<const EngineParams *>(plan.params_dev));
         return hipGetLastError();
     };
-    if (ahead == 6) return launch(k_engine<6>);
-    if (ahead == 4) return launch(k_engine<4>);
+    if (plan.ahead == 6) return launch(k_engine<6>);
+    if (plan.ahead == 4) return launch(k_engine<4>);
     return launch(k_engine<2>);
 }
 

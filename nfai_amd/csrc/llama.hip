@@ -51,6 +51,8 @@ struct Model {
     bool engine = false;             // requested: one engine launch per block where the tensors allow it
     uint64_t *d_gran = nullptr;      // engine hand-off granules: per block h (E) | act (F) | x (E)
     uint32_t *d_epoch = nullptr, *d_engerr = nullptr;
+    void *d_engparams = nullptr;     // one parameter block per block's engine launch
+    std::vector<EnginePlan> eng_plans;  // built by finalize when engine_ok
     Tensor token_embd, output_norm, output;
     std::vector<Layer> layers;  // index = block - layer_begin
     uint64_t kv_pos_stride = 0, kv_head_stride = 0;
@@ -386,7 +388,7 @@ bool engine_ok(const Model *m)
     if (!m->engine || m->unfused || !m->d_gran) return false;
     const nfai_llama_desc &d = m->d;
     const uint32_t HD = d.H * d.D;
-    if (d.E % 512 || d.F % 512 || HD % 512 || (d.Hkv * d.D) % 2) return false;
+    if (d.E % 512 || d.F % 512 || HD % 512 || (d.Hkv * d.D) % 2 || d.E > 4096 || HD > 4096) return false;
     if ((2 * (size_t)d.E + std::max(HD, d.F)) * 4 + 2048 + 5 * 8 * 1024 > 160 * 1024) return false;  // LDS: vectors + a 5-slot ring
     for (const Layer &L : m->layers)
         for (const Tensor *t : {&L.wq, &L.wk, &L.wv, &L.wo, &L.wgate, &L.wup, &L.wdown})
@@ -456,7 +458,7 @@ int enqueue_token(Model *m, bool with_head)
     }
     Sched sch{m, rec};
     const float *x_final = m->x;
-    if (engine_ok(m)) {
+    if (engine_ok(m) && m->eng_plans.size() == m->layers.size()) {
         // [q|k|v of the first block] then per block [attention] [engine: Wo -> gate|up -> Wdown -> next block's q|k|v].
         // The block input / output alternate between m->x and m->h so that no CU overwrites a vector another CU still reads.
         S_TRY(submit_qkv(m, m->layers[0], m->x, sch));
@@ -464,29 +466,8 @@ int enqueue_token(Model *m, bool with_head)
             Layer &L = m->layers[i];
             float *xin = (i & 1) ? m->h : m->x, *xout = (i & 1) ? m->x : m->h;
             S_TRY(submit_attn(m, L, sch));
-            EngineArgs e;
-            const bool more = i + 1 < m->layers.size();
-            e.n_ops = more ? 4 : 3;
-            e.E = d.E; e.F = d.F; e.HD = d.H * d.D;
-            e.Wo = L.wo.ptr; e.Wgate = L.wgate.ptr; e.Wup = L.wup.ptr; e.Wdown = L.wdown.ptr;
-            e.att = m->att; e.x_in = xin; e.x_out = xout;
-            e.gamma_ffn = static_cast<const float *>(L.ffn_norm.ptr);
-            e.eps = d.eps;
-            uint64_t *gl = m->d_gran + i * (2 * (size_t)d.E + d.F);
-            e.g_h = gl; e.g_act = gl + d.E; e.g_x = gl + d.E + d.F;
-            e.epoch = m->d_epoch; e.err = m->d_engerr;
-            e.n_cu = (uint32_t)m->ctx->prop.multiProcessorCount;
-            if (more) {
-                Layer &N = m->layers[i + 1];
-                e.gamma_next = static_cast<const float *>(N.attn_norm.ptr);
-                e.Wqkv[0] = N.wq.ptr; e.Wqkv[1] = N.wk.ptr; e.Wqkv[2] = N.wv.ptr;
-                e.qkv_rows[0] = (uint32_t)N.wq.rows; e.qkv_rows[1] = (uint32_t)N.wk.rows; e.qkv_rows[2] = (uint32_t)N.wv.rows;
-                e.q_out = m->q; e.kcache = N.kcache; e.vcache = N.vcache;
-                e.kv_type = m->kv_f16 ? NFAI_F16 : NFAI_F32;
-                e.kv_pos_stride = m->kv_pos_stride; e.kv_head_stride = m->kv_head_stride;
-                e.rope_cs = m->d_ropecs; e.rope_dims = d.rope_dims; e.D = d.D; e.pos_dev = m->d_pos;
-            }
-            S_TRY(sch.submit(op_fn(KC_ENGINE, [e](hipStream_t st) { return launch_engine(e, st); })));
+            const EnginePlan plan = m->eng_plans[i];
+            S_TRY(sch.submit(op_fn(KC_ENGINE, [plan](hipStream_t st) { return launch_engine(plan, st); })));
             x_final = xout;
         }
     } else {
@@ -553,6 +534,49 @@ int set_token_async(Model *m, uint32_t tok)
 {
     // Pageable source: hipMemcpyAsync stages it before returning, so a stack value is safe.
     HIP_TRY(hipMemcpyAsync(m->d_tok, &tok, 4, hipMemcpyHostToDevice, m->ctx->stream));
+    return NFAI_OK;
+}
+
+// The engine launch of every block: parameter blocks written to device memory once (finalize), launched from the token graph.
+int build_engine_plans(Model *m)
+{
+    m->eng_plans.clear();
+    if (!engine_ok(m)) return NFAI_OK;
+    const nfai_llama_desc &d = m->d;
+    const size_t pb = engine_params_bytes();
+    if (!m->d_engparams) DALLOC(m->d_engparams, pb * m->layers.size());
+    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    for (size_t i = 0; i < m->layers.size(); i++) {
+        Layer &L = m->layers[i];
+        float *xin = (i & 1) ? m->h : m->x, *xout = (i & 1) ? m->x : m->h;
+        EngineArgs e;
+        const bool more = i + 1 < m->layers.size();
+        e.n_ops = more ? 4 : 3;
+        e.E = d.E; e.F = d.F; e.HD = d.H * d.D;
+        e.Wo = L.wo.ptr; e.Wgate = L.wgate.ptr; e.Wup = L.wup.ptr; e.Wdown = L.wdown.ptr;
+        e.att = m->att; e.x_in = xin; e.x_out = xout;
+        e.gamma_ffn = static_cast<const float *>(L.ffn_norm.ptr);
+        e.eps = d.eps;
+        uint64_t *gl = m->d_gran + i * (2 * (size_t)d.E + d.F);
+        e.g_h = gl; e.g_act = gl + d.E; e.g_x = gl + d.E + d.F;
+        e.epoch = m->d_epoch; e.err = m->d_engerr;
+        e.n_cu = (uint32_t)m->ctx->prop.multiProcessorCount;
+        if (more) {
+            Layer &N = m->layers[i + 1];
+            e.gamma_next = static_cast<const float *>(N.attn_norm.ptr);
+            e.Wqkv[0] = N.wq.ptr; e.Wqkv[1] = N.wk.ptr; e.Wqkv[2] = N.wv.ptr;
+            e.qkv_rows[0] = (uint32_t)N.wq.rows; e.qkv_rows[1] = (uint32_t)N.wk.rows; e.qkv_rows[2] = (uint32_t)N.wv.rows;
+            e.q_out = m->q; e.kcache = N.kcache; e.vcache = N.vcache;
+            e.kv_type = m->kv_f16 ? NFAI_F16 : NFAI_F32;
+            e.kv_pos_stride = m->kv_pos_stride; e.kv_head_stride = m->kv_head_stride;
+            e.rope_cs = m->d_ropecs; e.rope_dims = d.rope_dims; e.D = d.D; e.pos_dev = m->d_pos;
+        }
+        EnginePlan plan;
+        hipError_t he = engine_plan(e, static_cast<char *>(m->d_engparams) + i * pb, plan);
+        if (he == hipErrorInvalidValue) { m->eng_plans.clear(); return NFAI_OK; }  // a shape the engine does not take: five launches
+        if (he != hipSuccess) return fail(NFAI_ERR_HIP, "engine_plan failed: %s", hipGetErrorString(he));
+        m->eng_plans.push_back(plan);
+    }
     return NFAI_OK;
 }
 
@@ -696,7 +720,7 @@ NFAI_API int32_t nfai_hip_llama_destroy(nfai_model_t h)
         free_t(L.ffn_norm); free_t(L.wgate); free_t(L.wup); free_t(L.wdown);
         hipFree(L.kcache); hipFree(L.vcache);
     }
-    void *ptrs[] = {m->d_gran, m->d_epoch, m->d_engerr, m->d_pos, m->d_tok, m->d_ring, m->d_freqs, m->d_ropecs, m->d_argmax_part, m->d_attn_part, m->x, m->h,
+    void *ptrs[] = {m->d_engparams, m->d_gran, m->d_epoch, m->d_engerr, m->d_pos, m->d_tok, m->d_ring, m->d_freqs, m->d_ropecs, m->d_argmax_part, m->d_attn_part, m->x, m->h,
                     m->q, m->att, m->act, m->logits, m->xn, m->qraw, m->scores, m->wts, m->proj, m->gate, m->up};
     for (void *p : ptrs) if (p) hipFree(p);
     void *pfp[] = {m->pf.toks, m->pf.X, m->pf.H1, m->pf.Q, m->pf.K, m->pf.V, m->pf.ATT, m->pf.G, m->pf.U, m->pf.SC,
@@ -845,6 +869,9 @@ NFAI_API int32_t nfai_hip_llama_finalize(nfai_model_t h)
     }
     if (m->graph_exec) { hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
     if (m->graph) { hipGraphDestroy(m->graph); m->graph = nullptr; }
+    if (m->stage_exec) { hipGraphExecDestroy(m->stage_exec); m->stage_exec = nullptr; }
+    if (m->stage_graph) { hipGraphDestroy(m->stage_graph); m->stage_graph = nullptr; }
+    if ((rc = build_engine_plans(m))) return rc;
     m->finalized = true;
     return NFAI_OK;
 }
