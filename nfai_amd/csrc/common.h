@@ -195,8 +195,9 @@ struct EngineArgs {
     uint32_t *err = nullptr;         // device word: non-zero after a bounded wait gave up
     uint32_t n_cu = 256;
 };
-struct EnginePlan {  // a planned engine launch: its parameter block in device memory + the launch geometry
+struct EnginePlan {  // a planned engine launch: the op table in device memory, the kernel argument, the launch geometry
     void *params_dev = nullptr;
+    alignas(8) unsigned char params[256] = {};
     uint32_t lds_bytes = 0, n_cu = 0;
     int ahead = 0;
 };

@@ -27,6 +27,7 @@
 // no atomics on the value path, every sum has a fixed order.
 // Every wait is bounded: on a timeout the workgroup raises `err`, sets its abort word and every wave leaves its loops.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -56,8 +57,10 @@ struct EngOp {
     float *y_plain;        // plain copy of the outputs for the NEXT launch (RESIDUAL), or null
 };
 
-struct EngineParams {
-    EngOp op[ENG_MAX_OPS];
+struct EngineParams {   // by value in the kernel argument: constant loads the compiler may keep in SGPRs across the asm waits
+    const EngOp *ops;    // [n_ops] in device memory: op i is picked with a run-time index (a run-time index into the by-value
+                         // argument would make hipcc copy the whole block to scratch; scratch accesses count on vmcnt, which the
+                         // loader counts by hand); each wave copies the op it works on into registers once
     uint32_t n_ops;
     uint32_t E, F, HD;
     const float *att;        // [HD]  attention output of this block (plain, written by the previous launch)
@@ -234,7 +237,7 @@ __device__ __forceinline__ void eng_loader(const EngineParams &p, uint8_t *lds, 
         }
     };
     for (uint32_t oi = 0; oi < p.n_ops && ok; oi++) {
-        const EngOp &o = p.op[oi];
+        const EngOp o = p.ops[oi];  // a register copy: not re-read behind every asm wait
         uint32_t ub, ue;
         eng_unit_range(o.NU, ub, ue);
         const uint32_t KC = o.K >> 9, nu = ue - ub;
@@ -449,7 +452,7 @@ __device__ __forceinline__ void eng_consumer(const EngineParams &p, uint8_t *lds
     bool ok = c.meet();
     uint32_t gbase = 0;   // first piece of the current op
     for (uint32_t oi = 0; oi < p.n_ops && ok; oi++) {
-        const EngOp &o = p.op[oi];
+        const EngOp o = p.ops[oi];  // a register copy: not re-read behind every asm wait
         uint32_t ub, ue;
         eng_unit_range(o.NU, ub, ue);
         const uint32_t KC = o.K >> 9, nu = ue - ub;
@@ -535,7 +538,7 @@ __device__ __forceinline__ void eng_consumer(const EngineParams &p, uint8_t *lds
         // nothing before this wave's first piece of the next op will be read by it again: the loader may run on while
         // this wave gathers
         if (oi + 1 < p.n_ops) {
-            const EngOp &nx = p.op[oi + 1];
+            const EngOp nx = p.ops[oi + 1];
             uint32_t nb, ne;
             eng_unit_range(nx.NU, nb, ne);
             const uint32_t nKC = nx.K >> 9, nnu = ne - nb;
@@ -558,13 +561,9 @@ __device__ __forceinline__ void eng_consumer(const EngineParams &p, uint8_t *lds
     STAMP_FLUSH(p.stamps, blockIdx.x * ENG_WAVES + 1 + w, 8);
 }
 
-// The parameters live in device memory (written once when the launch is planned): op i is picked with a run-time index, and a
-// run-time index into a by-value kernel argument would make hipcc copy the whole argument block to scratch (scratch accesses
-// count on vmcnt, which the loader counts by hand).
 template <int AHEAD>
-__global__ __launch_bounds__(ENG_THREADS) void k_engine(const EngineParams *__restrict__ pp)
+__global__ __launch_bounds__(ENG_THREADS) void k_engine(const EngineParams p)
 {
-    const EngineParams &p = *pp;
     extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -579,12 +578,13 @@ __global__ __launch_bounds__(ENG_THREADS) void k_engine(const EngineParams *__re
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
-size_t engine_params_bytes() { return (sizeof(EngineParams) + 255) & ~(size_t)255; }
+size_t engine_params_bytes() { return (sizeof(EngOp) * ENG_MAX_OPS + 255) & ~(size_t)255; }
 
 // Fill the launch's parameter block and copy it to `params_dev` (synchronous: call it outside stream capture, once per block).
 hipError_t engine_plan(const EngineArgs &a, void *params_dev, EnginePlan &plan)
 {
     EngineParams p{};
+    EngOp ops[ENG_MAX_OPS] = {};
     if (a.n_ops < 3 || a.n_ops > 4 || !params_dev) return hipErrorInvalidValue;
     const uint32_t E = a.E, F = a.F, HD = a.HD;
     if (E % 512 || F % 512 || HD % 512 || E % (128 * ENG_NC) || F % (128 * ENG_NC)) return hipErrorInvalidValue;
@@ -592,22 +592,22 @@ hipError_t engine_plan(const EngineArgs &a, void *params_dev, EnginePlan &plan)
     p.n_ops = a.n_ops;
     p.E = E; p.F = F; p.HD = HD;
     // op 0: Wo + residual
-    p.op[0].W[0] = static_cast<const uint8_t *>(a.Wo); p.op[0].K = HD; p.op[0].NU = E / 2; p.op[0].mode = ENG_RESIDUAL;
-    p.op[0].x_sel = 1; p.op[0].g_out = a.g_h; p.op[0].y_plain = nullptr;
+    ops[0].W[0] = static_cast<const uint8_t *>(a.Wo); ops[0].K = HD; ops[0].NU = E / 2; ops[0].mode = ENG_RESIDUAL;
+    ops[0].x_sel = 1; ops[0].g_out = a.g_h; ops[0].y_plain = nullptr;
     // op 1: gate | up
-    p.op[1].W[0] = static_cast<const uint8_t *>(a.Wgate); p.op[1].W[1] = static_cast<const uint8_t *>(a.Wup);
-    p.op[1].K = E; p.op[1].NU = F; p.op[1].mode = ENG_GATEUP; p.op[1].x_sel = 0; p.op[1].g_out = a.g_act;
+    ops[1].W[0] = static_cast<const uint8_t *>(a.Wgate); ops[1].W[1] = static_cast<const uint8_t *>(a.Wup);
+    ops[1].K = E; ops[1].NU = F; ops[1].mode = ENG_GATEUP; ops[1].x_sel = 0; ops[1].g_out = a.g_act;
     // op 2: Wdown + residual
-    p.op[2].W[0] = static_cast<const uint8_t *>(a.Wdown); p.op[2].K = F; p.op[2].NU = E / 2; p.op[2].mode = ENG_RESIDUAL;
-    p.op[2].x_sel = 1; p.op[2].g_out = a.n_ops == 4 ? a.g_x : nullptr; p.op[2].y_plain = a.x_out;
+    ops[2].W[0] = static_cast<const uint8_t *>(a.Wdown); ops[2].K = F; ops[2].NU = E / 2; ops[2].mode = ENG_RESIDUAL;
+    ops[2].x_sel = 1; ops[2].g_out = a.n_ops == 4 ? a.g_x : nullptr; ops[2].y_plain = a.x_out;
     if (a.n_ops == 4) {
         const uint32_t rows = a.qkv_rows[0] + a.qkv_rows[1] + a.qkv_rows[2];
         if ((a.qkv_rows[0] | a.qkv_rows[1] | a.qkv_rows[2] | a.D) & 1u) return hipErrorInvalidValue;
-        for (int i = 0; i < 3; i++) p.op[3].W[i] = static_cast<const uint8_t *>(a.Wqkv[i]);
-        p.op[3].seg_end[0] = a.qkv_rows[0];
-        p.op[3].seg_end[1] = a.qkv_rows[0] + a.qkv_rows[1];
-        p.op[3].seg_end[2] = rows;
-        p.op[3].K = E; p.op[3].NU = rows / 2; p.op[3].mode = ENG_QKV; p.op[3].x_sel = 0;
+        for (int i = 0; i < 3; i++) ops[3].W[i] = static_cast<const uint8_t *>(a.Wqkv[i]);
+        ops[3].seg_end[0] = a.qkv_rows[0];
+        ops[3].seg_end[1] = a.qkv_rows[0] + a.qkv_rows[1];
+        ops[3].seg_end[2] = rows;
+        ops[3].K = E; ops[3].NU = rows / 2; ops[3].mode = ENG_QKV; ops[3].x_sel = 0;
     }
     p.att = a.att; p.x_in = a.x_in; p.gamma_ffn = a.gamma_ffn; p.gamma_next = a.gamma_next; p.eps = a.eps;
     p.g_h = a.g_h; p.g_act = a.g_act; p.g_x = a.g_x; p.epoch = a.epoch;
@@ -635,8 +635,11 @@ hipError_t engine_plan(const EngineArgs &a, void *params_dev, EnginePlan &plan)
     plan.ahead = ahead;
     plan.n_cu = a.n_cu;
     plan.params_dev = params_dev;
+    p.ops = static_cast<const EngOp *>(params_dev);
     NFAI_STAMP_SET(p, "engine", a.n_cu, ENG_THREADS);
-    return hipMemcpy(params_dev, &p, sizeof(p), hipMemcpyHostToDevice);
+    static_assert(sizeof(EngineParams) <= sizeof(plan.params), "EnginePlan::params holds the kernel argument");
+    memcpy(plan.params, &p, sizeof(p));
+    return hipMemcpy(params_dev, ops, sizeof(ops), hipMemcpyHostToDevice);
 }
 
 hipError_t launch_engine(const EnginePlan &plan, hipStream_t s)
@@ -649,7 +652,9 @@ hipError_t launch_engine(const EnginePlan &plan, hipStream_t s)
             if (e != hipSuccess) return e;
             attr_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3(plan.n_cu), dim3(ENG_THREADS), plan.lds_bytes, s, static_cast<const EngineParams *>(plan.params_dev));
+        EngineParams p;
+        memcpy(&p, plan.params, sizeof(p));
+        hipLaunchKernelGGL(kern, dim3(plan.n_cu), dim3(ENG_THREADS), plan.lds_bytes, s, p);
         return hipGetLastError();
     };
     if (plan.ahead == 6) return launch(k_engine<6>);
