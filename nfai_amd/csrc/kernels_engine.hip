@@ -143,6 +143,21 @@ template <int N> __device__ __forceinline__ void eng_wait_vmcnt()
     else asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
 }
 
+// Op i of the launch as a register copy.  The table was written before the launch and nobody writes it: read through the
+// CONSTANT address space, so that hipcc uses scalar loads (through a plain global pointer it emits a vector load and waits
+// vmcnt(0) for it: a memory round trip on every op boundary, and in the loader a drain of the LDS-DMAs in flight).
+__device__ __forceinline__ EngOp eng_load_op(const EngOp *ops, uint32_t i)
+{
+    typedef const uint32_t __attribute__((address_space(4))) cu32;
+    EngOp o;
+    cu32 *src = (cu32 *)(ops + i);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&o);
+    static_assert(sizeof(EngOp) % 4 == 0, "copied as dwords");
+#pragma unroll
+    for (uint32_t k = 0; k < sizeof(EngOp) / 4; k++) dst[k] = src[k];
+    return o;
+}
+
 __device__ __forceinline__ void eng_unit_range(uint32_t NU, uint32_t &ub, uint32_t &ue)
 {
     ub = (uint32_t)(((uint64_t)NU * blockIdx.x) / gridDim.x);
@@ -186,6 +201,7 @@ __device__ __forceinline__ void eng_loader(const EngineParams &p, uint8_t *lds, 
     uint32_t min_rel = 0;         // last value seen of the consumers' smallest release mark
     LDS_AS uint8_t *ring = (LDS_AS uint8_t *)(lds + p.ring_off);
     bool ok = true;
+    __builtin_amdgcn_s_setprio(3);  // the loader's few scalar / memory instructions go first on the SIMD it shares with a consumer
     STAMP_DECL;
     STAMP(0);  // loader: start | last piece of op 0..3 issued (1..4) | everything landed (5)
 #ifdef NFAI_STAMPS
@@ -212,9 +228,15 @@ __device__ __forceinline__ void eng_loader(const EngineParams &p, uint8_t *lds, 
                 if (!ok) break;
             }
             const uint32_t run = min(n, (uint32_t)ENG_SLOT - within);
-            for (uint32_t j = 0; j < run; j++) {
-                __builtin_amdgcn_global_load_lds(src, ring + (rp + j) * 1024, 16, 0, 2);  // aux 2 = nt
-                src += 1024;
+            // the instruction's immediate offset applies to the global AND the LDS address: up to four pieces per address pair
+            for (uint32_t j = 0; j < run; j += 4) {
+                LDS_AS uint8_t *dst = ring + (rp + j) * 1024;
+                const uint32_t m = run - j;
+                __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 2);  // aux 2 = nt
+                if (m > 1) __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 2);
+                if (m > 2) __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 2);
+                if (m > 3) __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 2);
+                src += 4096;
             }
             n -= run;
             rp += run;
@@ -237,7 +259,7 @@ __device__ __forceinline__ void eng_loader(const EngineParams &p, uint8_t *lds, 
         }
     };
     for (uint32_t oi = 0; oi < p.n_ops && ok; oi++) {
-        const EngOp o = p.ops[oi];  // a register copy: not re-read behind every asm wait
+        const EngOp o = eng_load_op(p.ops, oi);
         uint32_t ub, ue;
         eng_unit_range(o.NU, ub, ue);
         const uint32_t KC = o.K >> 9, nu = ue - ub;
@@ -452,7 +474,7 @@ __device__ __forceinline__ void eng_consumer(const EngineParams &p, uint8_t *lds
     bool ok = c.meet();
     uint32_t gbase = 0;   // first piece of the current op
     for (uint32_t oi = 0; oi < p.n_ops && ok; oi++) {
-        const EngOp o = p.ops[oi];  // a register copy: not re-read behind every asm wait
+        const EngOp o = eng_load_op(p.ops, oi);
         uint32_t ub, ue;
         eng_unit_range(o.NU, ub, ue);
         const uint32_t KC = o.K >> 9, nu = ue - ub;
@@ -538,7 +560,7 @@ __device__ __forceinline__ void eng_consumer(const EngineParams &p, uint8_t *lds
         // nothing before this wave's first piece of the next op will be read by it again: the loader may run on while
         // this wave gathers
         if (oi + 1 < p.n_ops) {
-            const EngOp nx = p.ops[oi + 1];
+            const EngOp nx = eng_load_op(p.ops, oi + 1);
             uint32_t nb, ne;
             eng_unit_range(nx.NU, nb, ne);
             const uint32_t nKC = nx.K >> 9, nnu = ne - nb;
