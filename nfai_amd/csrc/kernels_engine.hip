@@ -149,12 +149,13 @@ template <int N> __device__ __forceinline__ void eng_wait_vmcnt()
 __device__ __forceinline__ EngOp eng_load_op(const EngOp *ops, uint32_t i)
 {
     typedef const uint32_t __attribute__((address_space(4))) cu32;
-    EngOp o;
-    cu32 *src = (cu32 *)(ops + i);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(&o);
     static_assert(sizeof(EngOp) % 4 == 0, "copied as dwords");
+    cu32 *src = (cu32 *)(ops + i);
+    uint32_t tmp[sizeof(EngOp) / 4];
 #pragma unroll
-    for (uint32_t k = 0; k < sizeof(EngOp) / 4; k++) dst[k] = src[k];
+    for (uint32_t k = 0; k < sizeof(EngOp) / 4; k++) tmp[k] = src[k];
+    EngOp o;
+    __builtin_memcpy(&o, tmp, sizeof(o));  // not a uint32_t* view of the struct: that would be an aliasing violation (undefined pointers)
     return o;
 }
 
@@ -228,16 +229,24 @@ __device__ __forceinline__ void eng_loader(const EngineParams &p, uint8_t *lds, 
                 if (!ok) break;
             }
             const uint32_t run = min(n, (uint32_t)ENG_SLOT - within);
+#if 0  // one address pair per piece (kept for reference: 7 instructions per piece instead of ~3)
+            for (uint32_t j = 0; j < run; j++) {
+                __builtin_amdgcn_global_load_lds(src, ring + (rp + j) * 1024, 16, 0, 2);  // aux 2 = nt
+                src += 1024;
+            }
+#else
             // the instruction's immediate offset applies to the global AND the LDS address: up to four pieces per address pair
             for (uint32_t j = 0; j < run; j += 4) {
+                const GLOBAL_AS uint8_t *sp = src + (uint64_t)j * 1024;
                 LDS_AS uint8_t *dst = ring + (rp + j) * 1024;
                 const uint32_t m = run - j;
-                __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 2);  // aux 2 = nt
-                if (m > 1) __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 2);
-                if (m > 2) __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 2);
-                if (m > 3) __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 2);
-                src += 4096;
+                __builtin_amdgcn_global_load_lds(sp, dst, 16, 0, 2);  // aux 2 = nt
+                if (m > 1) __builtin_amdgcn_global_load_lds(sp, dst, 16, 1024, 2);
+                if (m > 2) __builtin_amdgcn_global_load_lds(sp, dst, 16, 2048, 2);
+                if (m > 3) __builtin_amdgcn_global_load_lds(sp, dst, 16, 3072, 2);
             }
+            src += (uint64_t)run * 1024;
+#endif
             n -= run;
             rp += run;
             within += run;
