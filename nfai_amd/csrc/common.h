@@ -199,7 +199,7 @@ struct EnginePlan {  // a planned engine launch: the op table in device memory, 
     void *params_dev = nullptr;
     alignas(8) unsigned char params[256] = {};
     uint32_t lds_bytes = 0, n_cu = 0;
-    int ahead = 0;
+    int ahead = 0;  // U: chunks per step (4, 6 or 8 = embedding width / 512)
 };
 size_t engine_params_bytes();
 hipError_t engine_plan(const EngineArgs &a, void *params_dev, EnginePlan &plan);  // synchronous copy: outside stream capture

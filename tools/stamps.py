@@ -78,33 +78,31 @@ def main():
     # one token = the slots captured in the graph, in launch order
     per_cls = {}
     launches = []
-    eng = {"loader": [], "consumer": []}
-    eng_span, eng_wait = [], []
+    eng = {"stream": [], "control": []}
+    eng_span = []
+    NS = 8  # stream waves per workgroup (kernels_engine.hip: ENG_NS), the rest are control waves
     for s, (name, grid, block) in enumerate(infos):
         if name != "engine":
             continue
         nw = block // 64
         t = st[s][: grid * nw].reshape(grid, nw, WORDS)
-        ev = np.concatenate([t[:, 0, :6].reshape(-1), t[:, 1:, :].reshape(-1)])
-        t0 = ev[ev > 0].min()
+        t0 = t[t > 0].min()
         rel = np.where(t > 0, t - t0, np.nan)
-        eng["loader"].append(rel[:, 0, :6])
-        eng["consumer"].append(rel[:, 1:, :].reshape(-1, 8))
-        eng_wait.append(t[:, 0, 6:8])  # loader: us spent waiting for a free slot / for loads to land (durations, not times)
-        eng_span.append(float(np.nanmax(np.concatenate([rel[:, 0, :6].reshape(-1), rel[:, 1:, :].reshape(-1)]))))
+        eng["stream"].append(rel[:, :NS, :].reshape(-1, 8))
+        eng["control"].append(rel[:, NS:, :].reshape(-1, 8))
+        eng_span.append(float(np.nanmax(rel)))
     if eng_span:
         def med(rows, k):
             a_ = np.concatenate(rows)[:, k]
             a_ = a_[~np.isnan(a_)]
-            return pct(a_) if a_.size else None
-        names = {"loader": ["start", "op0 (Wo) issued", "op1 (gate|up) issued", "op2 (Wdown) issued", "op3 (next q|k|v) issued", "all landed"],
-                 "consumer": ["att/x in LDS, op0 starts", "op0 done", "h gathered + normalised, op1 starts", "op1 done", "act gathered, op2 starts",
-                              "op2 done", "x' gathered + normalised, op3 starts", "op3 done"]}
-        w = np.concatenate(eng_wait)
-        print(json.dumps({"what": "engine launch (kernels_engine.hip): time of each event since the launch's first stamp, us, [median, p10, p90] "
-                                  "over the workgroups (x consumer waves) of all blocks' launches in one token", "model": a.model,
+            return (pct(a_) + [round(float(a_.max()), 3)]) if a_.size else None
+        names = {"stream": ["x of op0 (Wo) seen", "op0 done", "x of op1 (gate|up) seen", "op1 done", "x of op2 (Wdown) seen", "op2 done",
+                            "x of op3 (next q|k|v) seen", "op3 done"],
+                 "control": ["start", "att / x in LDS", "local stream waves done op0", "h gathered + normalised", "local done op1", "act gathered",
+                             "local done op2", "x' gathered + normalised"]}
+        print(json.dumps({"what": "engine launch (kernels_engine.hip): time of each event since the launch's first stamp, us, [median, p10, p90, max] "
+                                  "over the waves of that role of all workgroups of all blocks' launches in one token", "model": a.model,
                           "launches": len(eng_span), "span_us": pct(eng_span),
-                          "loader_waiting_us": {"for a free ring slot (consumers)": pct(w[:, 0]), "for loads to land (memory)": pct(w[:, 1])},
                           "roles": {r: {names[r][k]: med(v, k) for k in range(len(names[r]))} for r, v in eng.items()}}, indent=1))
         return
     for s, (name, grid, block) in enumerate(infos):
