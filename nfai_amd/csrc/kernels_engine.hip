@@ -559,7 +559,7 @@ hipError_t engine_plan(const EngineArgs &a, void *params_dev, EnginePlan &plan)
     plan.lds_bytes = p.cs_off + 1024;
     if (plan.lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     // step = U chunks of one row: U = 512-weight chunks of a row of the projections from the embedding width
-    if (E != HD || (E / 512 != 4 && E / 512 != 6 && E / 512 != 8)) return hipErrorInvalidValue;
+    if (E != HD || (E / 512 != 1 && E / 512 != 2 && E / 512 != 4 && E / 512 != 6 && E / 512 != 8)) return hipErrorInvalidValue;
     plan.ahead = (int)(E / 512);
     plan.n_cu = a.n_cu;
     plan.params_dev = params_dev;
@@ -585,6 +585,8 @@ hipError_t launch_engine(const EnginePlan &plan, hipStream_t s)
         hipLaunchKernelGGL(kern, dim3(plan.n_cu), dim3(ENG_THREADS), plan.lds_bytes, s, p);
         return hipGetLastError();
     };
+    if (plan.ahead == 1) return launch(k_engine<1>);
+    if (plan.ahead == 2) return launch(k_engine<2>);
     if (plan.ahead == 4) return launch(k_engine<4>);
     if (plan.ahead == 6) return launch(k_engine<6>);
     return launch(k_engine<8>);

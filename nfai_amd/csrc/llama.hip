@@ -388,7 +388,7 @@ bool engine_ok(const Model *m)
     if (!m->engine || m->unfused || !m->d_gran) return false;
     const nfai_llama_desc &d = m->d;
     const uint32_t HD = d.H * d.D;
-    if (d.E % 512 || d.F % 512 || HD != d.E || (d.Hkv * d.D) % 2 || (d.E != 2048 && d.E != 3072 && d.E != 4096)) return false;
+    if (d.E % 512 || d.F % 512 || HD != d.E || (d.Hkv * d.D) % 2 || (d.E != 512 && d.E != 1024 && d.E != 2048 && d.E != 3072 && d.E != 4096)) return false;
     if ((2 * (size_t)d.E + std::max(HD, d.F)) * 4 + 2048 > 160 * 1024 || d.D > 128) return false;  // LDS: the three activation vectors
     for (const Layer &L : m->layers)
         for (const Tensor *t : {&L.wq, &L.wk, &L.wv, &L.wo, &L.wgate, &L.wup, &L.wdown})
