@@ -34,7 +34,7 @@ int fail(int code, const char *fmt, ...);
 // Every wave of a stamped kernel records up to 8 readings of s_memrealtime (100 MHz, one clock for the whole chip) into its
 // launch's slot of a buffer the tool hands in; no stamp exists in the product build (MI355X guide, "In-kernel stamps").
 #ifdef NFAI_STAMPS
-constexpr uint32_t STAMP_WAVES = 2048, STAMP_WORDS = 8;
+constexpr uint32_t STAMP_WAVES = 4096, STAMP_WORDS = 8;
 struct StampSlot { char name[48]; uint32_t grid, block; };
 unsigned long long *stamp_next_slot(const char *name, uint32_t grid, uint32_t block);  // null when no buffer is installed
 #define NFAI_STAMP_PARAM unsigned long long *stamps;
@@ -317,7 +317,7 @@ __device__ __forceinline__ float dot8_f16(u32x4 w, f32x4 x0, f32x4 x1, float acc
 #ifdef NFAI_STAMPS
 // STAMP(i): reading i of this wave (wave-uniform scalar registers; written out by stamp_flush at the end of the kernel)
 struct Stamps {
-    unsigned long long t[STAMP_WORDS];
+    unsigned long long t[STAMP_WORDS] = {};
     __device__ __forceinline__ void at(int i) { __builtin_amdgcn_sched_barrier(0); t[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); }
     __device__ __forceinline__ void flush(unsigned long long *base, uint32_t wave_global, int n)
     {

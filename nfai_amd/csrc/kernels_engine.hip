@@ -81,7 +81,7 @@ struct EngineParams {   // by value in the kernel argument: constant loads the c
     const uint32_t *pos;
     int kv_f16;
     uint32_t *err;
-    uint32_t xa_off, xr_off, xb_off, cs_off;  // byte offsets in LDS
+    uint32_t xa_off, xr_off, xb_off, cs_off, part_off, cnt_off;  // byte offsets in LDS
     NFAI_STAMP_PARAM
 };
 
@@ -101,6 +101,7 @@ constexpr uint32_t W_ABORT = 0;     // non-zero: a wait gave up, everybody leave
 constexpr uint32_t W_XREADY = 4;    // ops whose activation vector is in LDS (monotonic)
 constexpr uint32_t W_DONE = 8;      // stream-wave completions, one per stream wave and op (monotonic)
 constexpr uint32_t W_ARRIVE = 12;   // the control waves' meeting counter (monotonic)
+constexpr uint32_t W_CTL_ISSUED = 16;  // control waves that have REQUESTED their first inputs (the stream waves' weight loads queue behind)
 constexpr uint32_t W_SS = 32;       // per control wave: its share of the sum of squares of the vector being gathered
 
 __device__ __forceinline__ bool eng_give_up(uint32_t *err, uint32_t code)
@@ -171,59 +172,57 @@ __device__ __forceinline__ void eng_publish(uint64_t *g, uint32_t idx, uint32_t 
 }
 
 // ---- stream waves -------------------------------------------------------------------------------------------------------
-// A wave's position in its flat sequence of steps: op, unit (local index ul = s, s + 8, ... of the CU's range), row of the
-// unit, first 1-KiB chunk of the step.  A step = U consecutive chunks of ONE row (U = K/512 of the projections from the
-// embedding width: a whole row; the long rows of Wdown take several steps, the last one padded with re-reads of its last
-// chunk, which hit in cache), so the unrolled load / FMA code holds no per-piece bookkeeping.  All wave-uniform.  One cursor
-// issues loads NB - 1 steps ahead, one consumes.
+// Work item = one STEP = U consecutive 1-KiB chunks of ONE row (U = K/512 of the projections from the embedding width: a whole
+// row; the long rows of Wdown are cut into ceil(KC / U) segments, the last one padded with re-reads of its last chunk, which
+// hit in cache), so the unrolled load / FMA code holds no per-piece bookkeeping.  The CU's items of an op — unit-major, then
+// row, then segment — go to its eight stream waves round-robin, whatever the op's shape (Wdown of Llama-3.2-3B: 12 rows x 3
+// segments = 36 items on a CU).  Every item ends in a partial sum in LDS and a count on the item's UNIT; the wave whose count
+// completes the unit adds the partial sums in fixed order (bit-reproducible) and runs the epilogue.
+//   item i of the op:  unit ul = i / (2 * nseg), row sub = (i / nseg) % 2, segment seg = i % nseg
+// One cursor issues loads two steps ahead of the one that consumes; both are wave-uniform.
+constexpr uint32_t ENG_MAX_UNITS = 64, ENG_MAX_SEG = 4;  // per CU and op (gate|up of Llama-3.1-8B: 56 units); Wdown row segments
+
 struct EngCursor {
-    uint32_t oi = 0, ul = 0, sub = 0, cseg = 0;
-    uint32_t ub = 0, nu = 0, KC = 1;
+    uint32_t oi = 0, i = 0, nitems = 0, nseg = 1, KC = 1, ub = 0;
+    uint32_t ul = 0, sub = 0, seg = 0;  // of item i
     bool end = false;
     EngOp o;
-    const GLOBAL_AS uint8_t *row = nullptr;  // base of the current row + lane * 16
 };
 
-// Enter op `oi` (or the first later op in which this wave owns a unit).  `on_skip(op)` is called for every op the wave passes
+template <int U> __device__ __forceinline__ void eng_cursor_item(EngCursor &cu)
+{
+    const uint32_t q = cu.i / cu.nseg;
+    cu.seg = cu.i - q * cu.nseg;
+    cu.ul = q >> 1;
+    cu.sub = q & 1;
+}
+
+// Enter op `oi` (or the first later op in which this wave owns an item).  `on_skip(op)` is called for every op the wave passes
 // without work (the consuming cursor reports it done).
-template <typename F>
-__device__ __forceinline__ void eng_cursor_enter(EngCursor &cu, const EngineParams &p, uint32_t oi, uint32_t s, uint32_t lane, F on_skip)
+template <int U, typename F>
+__device__ __forceinline__ void eng_cursor_enter(EngCursor &cu, const EngineParams &p, uint32_t oi, uint32_t s, F on_skip)
 {
     for (;; oi++) {
         if (oi >= p.n_ops) { cu.end = true; cu.oi = oi; return; }
         cu.o = eng_load_op(p.ops, oi);
         uint32_t ue;
         eng_unit_range(cu.o.NU, cu.ub, ue);
-        cu.nu = ue - cu.ub;
         cu.KC = cu.o.K >> 9;
-        if (s < cu.nu) break;
+        cu.nseg = (cu.KC + U - 1) / U;
+        cu.nitems = (ue - cu.ub) * 2 * cu.nseg;
+        if (s < cu.nitems) break;
         on_skip(oi);
     }
-    cu.oi = oi; cu.ul = s; cu.sub = 0; cu.cseg = 0;
-    cu.row = eng_row(cu.o, cu.ub + cu.ul, 0) + lane * 16;
+    cu.oi = oi; cu.i = s;
+    eng_cursor_item<U>(cu);
 }
 
-// the step after the current one; true when it crossed the end of a unit (second row finished)
-template <int U, typename F>
-__device__ __forceinline__ bool eng_cursor_next(EngCursor &cu, const EngineParams &p, uint32_t s, uint32_t lane, F on_skip)
+// ONE add per wave (lane 0), the value before it for every lane
+__device__ __forceinline__ uint32_t lds_add_rtn(uint32_t addr, uint32_t v, uint32_t lane)
 {
-    cu.cseg += U;
-    if (cu.cseg < cu.KC) return false;
-    cu.cseg = 0;
-    if (cu.sub == 0) {
-        cu.sub = 1;
-        cu.row = eng_row(cu.o, cu.ub + cu.ul, 1) + lane * 16;
-        return false;
-    }
-    cu.sub = 0;
-    cu.ul += ENG_NS;
-    return true;  // the caller finishes the unit, then calls eng_cursor_unit
-}
-template <typename F>
-__device__ __forceinline__ void eng_cursor_unit(EngCursor &cu, const EngineParams &p, uint32_t s, uint32_t lane, F on_skip)
-{
-    if (cu.ul < cu.nu) cu.row = eng_row(cu.o, cu.ub + cu.ul, 0) + lane * 16;
-    else eng_cursor_enter(cu, p, cu.oi + 1, s, lane, on_skip);
+    uint32_t r = 0;
+    if (lane == 0) asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(addr), "v"(v) : "memory");
+    return __builtin_amdgcn_readfirstlane(r);
 }
 
 template <int U>
@@ -231,36 +230,44 @@ __device__ __forceinline__ void eng_stream(const EngineParams &p, uint8_t *lds, 
 {
     const float *XA = reinterpret_cast<const float *>(lds + p.xa_off), *XR = reinterpret_cast<const float *>(lds + p.xr_off);
     const float *XB = reinterpret_cast<const float *>(lds + p.xb_off), *CS = reinterpret_cast<const float *>(lds + p.cs_off);
+    float *PART = reinterpret_cast<float *>(lds + p.part_off);   // [op][unit][row][segment] partial sums
+    const uint32_t cnt_base = p.cnt_off;                          // [op][unit] arrival counts (zero at launch)
     const uint32_t pos = p.pos ? ((const GLOBAL_AS uint32_t *)p.pos)[0] : 0u;
-    STAMP_DECL;  // stream wave: activation of op i seen (2i) | this wave's last unit of op i finished (2i + 1)
+    STAMP_DECL;  // stream wave: activation of op i seen (2i) | this wave's last item of op i finished (2i + 1)
     EngCursor ic, cc;  // issuing / consuming
     auto skip_quiet = [](uint32_t) {};
     auto skip_done = [&](uint32_t) { if (lane == 0) lds_add(W_DONE, 1); };
-    eng_cursor_enter(ic, p, 0, s, lane, skip_quiet);
-    eng_cursor_enter(cc, p, 0, s, lane, skip_done);
-    if (cc.end) return;  // no unit in any op (tiny models): the passes above reported every op done
-    const GLOBAL_AS uint8_t *last_addr = ic.row;  // a valid address for the surplus loads behind the end of the sequence
+    eng_cursor_enter<U>(ic, p, 0, s, skip_quiet);
+    eng_cursor_enter<U>(cc, p, 0, s, skip_done);
+    if (cc.end) return;  // no item in any op (tiny models): the passes above reported every op done
+    const GLOBAL_AS uint8_t *last_addr = eng_row(ic.o, ic.ub, 0) + lane * 16;  // a valid address for the surplus loads behind the end
+    // A CU's memory requests are served in order: the control waves' first requests (the vectors op 0 waits for) go ahead of
+    // the ~140 KiB of weights this CU's stream waves are about to request (stamps: 7 us -> first FMA otherwise).
+    if (!lds_wait_ge(W_CTL_ISSUED, ENG_NCW, p.err, 0x800u)) return;
 
     // unconditional loads (behind the end of a row / of the sequence: re-reads of the last valid chunk): every
     // compiler-inserted vmcnt is an exact count
     auto issue = [&](u32x4 (&buf)[U]) {
-        const uint32_t nvalid = ic.end ? 1u : min((uint32_t)U, ic.KC - ic.cseg);
-        const GLOBAL_AS uint8_t *a = ic.end ? last_addr : ic.row + (uint64_t)ic.cseg * 1024;
+        const uint32_t c0 = ic.seg * U;
+        const uint32_t nvalid = ic.end ? 1u : min((uint32_t)U, ic.KC - c0);
+        const GLOBAL_AS uint8_t *a = ic.end ? last_addr : eng_row(ic.o, ic.ub + ic.ul, ic.sub) + lane * 16 + (uint64_t)c0 * 1024;
 #pragma unroll
         for (int j = 0; j < U; j++) buf[j] = load_nt16((const void *)(a + (uint64_t)min((uint32_t)j, nvalid - 1) * 1024));
         last_addr = a;
-        if (!ic.end && eng_cursor_next<U>(ic, p, s, lane, skip_quiet)) eng_cursor_unit(ic, p, s, lane, skip_quiet);
+        if (!ic.end) {
+            ic.i += ENG_NS;
+            if (ic.i < ic.nitems) eng_cursor_item<U>(ic);
+            else eng_cursor_enter<U>(ic, p, ic.oi + 1, s, skip_quiet);
+        }
     };
 
     bool ok = true;
     bool fresh_op = true;   // the consuming cursor has not yet checked that its op's activation vector is in LDS
     const float *xs = XA;
-    float acc = 0.f, a0 = 0.f;
+    // the unit's epilogue, by the wave whose item completed it; r0, r1 = the two row sums
     auto finish_unit = [&](float r0, float r1, uint32_t ul) {
         const EngOp &o = cc.o;
         const uint32_t u = cc.ub + ul;
-        r0 = wave_sum(r0);
-        r1 = wave_sum(r1);
         if (lane == 0) {
             if (o.mode == ENG_RESIDUAL) {
                 // host residual add of TransformerBlock.cs:153-158 / 176-180: input + projection
@@ -302,7 +309,7 @@ __device__ __forceinline__ void eng_stream(const EngineParams &p, uint8_t *lds, 
     auto consume = [&](u32x4 (&buf)[U]) {
         if (cc.end || !ok) return;  // surplus loads behind the end of the sequence
         if (fresh_op) {
-            // the first step of an op: its activation vector must be in LDS (the control waves flag it)
+            // the first item of an op: its activation vector must be in LDS (the control waves flag it)
             ok = lds_wait_ge(W_XREADY, cc.oi + 1, p.err, 0x20u);
             if (!ok) return;
             fresh_op = false;
@@ -311,8 +318,10 @@ __device__ __forceinline__ void eng_stream(const EngineParams &p, uint8_t *lds, 
             if (cc.oi == 0) STAMP(0); else if (cc.oi == 1) STAMP(2); else if (cc.oi == 2) STAMP(4); else STAMP(6);
 #endif
         }
-        const uint32_t nvalid = min((uint32_t)U, cc.KC - cc.cseg);
-        const float *xc = xs + (cc.cseg << 9) + (lane << 2);
+        const uint32_t c0 = cc.seg * U;
+        const uint32_t nvalid = min((uint32_t)U, cc.KC - c0);
+        const float *xc = xs + (c0 << 9) + (lane << 2);
+        float acc = 0.f;
 #pragma unroll
         for (int j = 0; j < U; j++) {
             if ((uint32_t)j < nvalid) {  // wave-uniform; nothing but LDS reads and FMAs inside
@@ -321,22 +330,28 @@ __device__ __forceinline__ void eng_stream(const EngineParams &p, uint8_t *lds, 
                 acc = dot8_f16(buf[j], x0, x1, acc);
             }
         }
-        const uint32_t ul = cc.ul;
-        const bool first_row_done = cc.sub == 0 && cc.cseg + U >= cc.KC;
-        if (eng_cursor_next<U>(cc, p, s, lane, skip_done)) {
-            finish_unit(a0, acc, ul);
-            acc = 0.f;
-            if (cc.ul >= cc.nu) {  // that was this wave's last unit of the op
+        acc = wave_sum(acc);
+        // partial sum of (unit, row, segment) -> LDS; count the item on its unit
+        const uint32_t slot = ((cc.oi * ENG_MAX_UNITS + cc.ul) * 2 + cc.sub) * ENG_MAX_SEG + cc.seg;
+        if (lane == 0) PART[slot] = acc;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint32_t arrived = lds_add_rtn(cnt_base + (cc.oi * ENG_MAX_UNITS + cc.ul) * 4, 1, lane);
+        if (arrived + 1 == 2 * cc.nseg) {  // this item completed its unit: every partial sum of the unit is in LDS
+            const float *pu = PART + (cc.oi * ENG_MAX_UNITS + cc.ul) * 2 * ENG_MAX_SEG;
+            float r0 = 0.f, r1 = 0.f;
+            for (uint32_t g = 0; g < cc.nseg; g++) { r0 += pu[g]; r1 += pu[ENG_MAX_SEG + g]; }  // fixed order
+            finish_unit(r0, r1, cc.ul);
+        }
+        cc.i += ENG_NS;
+        if (cc.i < cc.nitems) {
+            eng_cursor_item<U>(cc);
+        } else {  // that was this wave's last item of the op
 #ifdef NFAI_STAMPS
-                if (cc.oi == 0) STAMP(1); else if (cc.oi == 1) STAMP(3); else if (cc.oi == 2) STAMP(5); else STAMP(7);
+            if (cc.oi == 0) STAMP(1); else if (cc.oi == 1) STAMP(3); else if (cc.oi == 2) STAMP(5); else STAMP(7);
 #endif
-                if (lane == 0) lds_add(W_DONE, 1);
-                fresh_op = true;
-            }
-            eng_cursor_unit(cc, p, s, lane, skip_done);
-        } else if (first_row_done) {
-            a0 = acc;
-            acc = 0.f;
+            if (lane == 0) lds_add(W_DONE, 1);
+            fresh_op = true;
+            eng_cursor_enter<U>(cc, p, cc.oi + 1, s, skip_done);
         }
     };
 
@@ -464,6 +479,8 @@ __device__ __forceinline__ void eng_control(const EngineParams &p, uint8_t *lds,
     }
     f32x2 csv = f32x2{1.f, 0.f};
     if (p.rope_cs && cw == 0 && lane * 2 < p.D) csv = *reinterpret_cast<const GLOBAL_AS f32x2 *>((const GLOBAL_AS float *)p.rope_cs + lane * 2);
+    __builtin_amdgcn_sched_barrier(0);  // every request above is issued before the stream waves are let go
+    if (lane == 0) lds_add(W_CTL_ISSUED, 1);
 #pragma unroll
     for (int i = 0; i < ENG_NV; i++) {
         const uint32_t k = ((i * ENG_NCW + cw) * 64 + lane) * 4;
@@ -507,6 +524,7 @@ __global__ __launch_bounds__(ENG_THREADS) void k_engine(const EngineParams p)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // control words start at zero: wave 0 clears them, everyone meets once (the only workgroup barrier of the kernel)
     if (wave == 0) reinterpret_cast<uint32_t *>(lds)[lane] = 0;
+    for (uint32_t i = threadIdx.x; i < ENG_MAX_OPS * ENG_MAX_UNITS; i += ENG_THREADS) reinterpret_cast<uint32_t *>(lds + p.cnt_off)[i] = 0;
     __syncthreads();
     const uint32_t epoch = ((const GLOBAL_AS uint32_t *)p.epoch)[0];
     if (wave < ENG_NS) eng_stream<U>(p, lds, wave, lane, epoch);
@@ -556,7 +574,15 @@ hipError_t engine_plan(const EngineArgs &a, void *params_dev, EnginePlan &plan)
     p.xr_off = p.xa_off + E * 4;
     p.xb_off = p.xr_off + E * 4;
     p.cs_off = p.xb_off + xb * 4;
-    plan.lds_bytes = p.cs_off + 1024;
+    p.part_off = p.cs_off + 1024;                                                   // [op][unit][row][segment] floats
+    p.cnt_off = p.part_off + ENG_MAX_OPS * ENG_MAX_UNITS * 2 * ENG_MAX_SEG * 4;     // [op][unit] arrival counts
+    plan.lds_bytes = p.cnt_off + ENG_MAX_OPS * ENG_MAX_UNITS * 4;
+    // per CU and op: at most ENG_MAX_UNITS units, rows of at most ENG_MAX_SEG steps
+    {
+        const uint32_t U = E / 512;
+        for (uint32_t i = 0; i < a.n_ops; i++)
+            if ((ops[i].NU + a.n_cu - 1) / a.n_cu > ENG_MAX_UNITS || ((ops[i].K >> 9) + U - 1) / U > ENG_MAX_SEG) return hipErrorInvalidValue;
+    }
     if (plan.lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     // step = U chunks of one row: U = 512-weight chunks of a row of the projections from the embedding width
     if (E != HD || (E / 512 != 1 && E / 512 != 2 && E / 512 != 4 && E / 512 != 6 && E / 512 != 8)) return hipErrorInvalidValue;

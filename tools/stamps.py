@@ -53,7 +53,7 @@ def main():
     torch.cuda.set_device(0)
     weights = B.gen_weights_hbm(torch, dims, (0, dims.L), True, True, quant=a.quant)
     n_slots = dims.L * 6 + 8
-    WAVES, WORDS = 2048, 8
+    WAVES, WORDS = 4096, 8
     buf = torch.zeros(n_slots * WAVES * WORDS, device="cuda", dtype=torch.int64)
     lib.nfai_hip_debug_stamps_install.argtypes = [C.c_void_p, C.c_uint32]
     lib.nfai_hip_debug_stamps_info.argtypes = [C.c_uint32, C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
