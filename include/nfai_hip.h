@@ -182,8 +182,8 @@ int32_t nfai_hip_gemv_qkv_rope(nfai_ctx_t ctx, nfai_buf_t Wq, nfai_buf_t Wk, nfa
  * TransformerBlock (TransformerBlock.cs:150-181, then :129-141 of the next block) as ONE launch of the weight-streaming engine
  * (kernels_engine.hip), fp16 weights, E / F / HD multiples of 512, on caller-held buffers: the op-level form of what the model
  * enqueues per block under NFAI_LLAMA_ENGINE.  Wq == 0: the launch ends with Wdown.  K/V caches in the reference layout
- * [C][Hkv*D].  scratch: (2E + F + 3072) * 8 + 64 bytes, zeroed once by the caller (hand-off granules {value, tag} of h | act | x,
- * 3 x 1024 per-CU completion flags, then control words). */
+ * [C][Hkv*D].  scratch: (2E + F) * 8 + 64 bytes, zeroed once by the caller (hand-off granules {value, tag} of h | act | x, then
+ * control words). */
 int32_t nfai_hip_engine_block(nfai_ctx_t ctx, nfai_buf_t Wo, nfai_buf_t Wgate, nfai_buf_t Wup, nfai_buf_t Wdown, nfai_buf_t att,
                               nfai_buf_t x_in, nfai_buf_t gamma_ffn, float eps, uint32_t E, uint32_t F, uint32_t HD,
                               nfai_buf_t Wq, nfai_buf_t Wk, nfai_buf_t Wv, nfai_buf_t gamma_next, nfai_buf_t freqs,

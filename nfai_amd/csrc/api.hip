@@ -811,8 +811,7 @@ NFAI_API int32_t nfai_hip_gemv_qkv_rope(nfai_ctx_t h, nfai_buf_t Wq, nfai_buf_t 
 
 // One launch of the weight-streaming engine on caller-held buffers (tests / tools): what nfai_hip_llama_* enqueues per block when
 // NFAI_LLAMA_ENGINE is set.  `scratch` holds the hand-off granules h (E) | act (F) | x (E) (8 bytes each: value, tag) followed by
-// 3 x 1024 per-CU completion flags and 64 bytes of control words (epoch, error); the caller zeroes it once and may read the
-// granules' low words afterwards.
+// 64 bytes of control words (epoch, error); the caller zeroes it once and may read the granules' low words afterwards.
 NFAI_API int32_t nfai_hip_engine_block(nfai_ctx_t h, nfai_buf_t Wo, nfai_buf_t Wgate, nfai_buf_t Wup, nfai_buf_t Wdown, nfai_buf_t att,
                                        nfai_buf_t x_in, nfai_buf_t gamma_ffn, float eps, uint32_t E, uint32_t F, uint32_t HD,
                                        nfai_buf_t Wq, nfai_buf_t Wk, nfai_buf_t Wv, nfai_buf_t gamma_next, nfai_buf_t freqs,
@@ -838,7 +837,7 @@ NFAI_API int32_t nfai_hip_engine_block(nfai_ctx_t h, nfai_buf_t Wo, nfai_buf_t W
     NEED(bx, E, 4);
     NEED(bg, E, 4);
     NEED(bxo, E, 4);
-    const uint64_t ngran = 2ull * E + F + ENGINE_FLAG_GRANULES;
+    const uint64_t ngran = 2ull * E + F;
     NEED(bs, ngran * 8 + 64, 1);
     uint64_t *gr = static_cast<uint64_t *>(bs->ptr);
     uint32_t *words = reinterpret_cast<uint32_t *>(gr + ngran);
@@ -849,7 +848,7 @@ NFAI_API int32_t nfai_hip_engine_block(nfai_ctx_t h, nfai_buf_t Wo, nfai_buf_t W
     e.x_in = static_cast<const float *>(bx->ptr);
     e.gamma_ffn = static_cast<const float *>(bg->ptr);
     e.eps = eps;
-    e.g_h = gr; e.g_act = gr + E; e.g_x = gr + E + F; e.g_flags = gr + 2ull * E + F;
+    e.g_h = gr; e.g_act = gr + E; e.g_x = gr + E + F;
     e.epoch = words; e.err = words + 1;
     e.x_out = static_cast<float *>(bxo->ptr);
     e.n_cu = (uint32_t)c->prop.multiProcessorCount;

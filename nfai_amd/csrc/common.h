@@ -183,7 +183,6 @@ struct EngineArgs {
     const float *att = nullptr, *x_in = nullptr, *gamma_ffn = nullptr, *gamma_next = nullptr;
     float eps = 0.f;
     uint64_t *g_h = nullptr, *g_act = nullptr, *g_x = nullptr;   // granule vectors (E, F, E), zero-initialised once
-    uint64_t *g_flags = nullptr;                                 // 3 x 1024 granules: per-CU completion flags of the three edges
     const uint32_t *epoch = nullptr;                             // device word, advanced once per token
     float *x_out = nullptr;          // plain [E]: the block's output
     float *q_out = nullptr;
@@ -205,7 +204,6 @@ struct EnginePlan {  // a planned engine launch: the op table in device memory, 
 size_t engine_params_bytes();
 hipError_t engine_plan(const EngineArgs &a, void *params_dev, EnginePlan &plan);  // synchronous copy: outside stream capture
 hipError_t launch_engine(const EnginePlan &plan, hipStream_t s);
-constexpr size_t ENGINE_FLAG_GRANULES = 3 * 1024;  // per engine launch, behind its h | act | x granules
 
 // basic 1:1 ops
 hipError_t launch_embed(const void *table, int type, const uint32_t *tok, float *y, uint32_t E, hipStream_t s);

@@ -46,7 +46,6 @@ constexpr int ENG_MAX_OPS = 4;
 constexpr int ENG_GL = 8;                   // 16-byte loads per lane and gather chunk
 constexpr int ENG_NGAMMA = 8;               // RMSNorm gains per lane of a control wave: E <= 128 * ENG_NCW * ENG_NGAMMA = 4096
 constexpr int ENG_NV = 4;                   // float4 per lane of a control wave for a plain vector: <= 4 * 64 * ENG_NCW * ENG_NV = 4096
-constexpr uint32_t ENG_FLAG_STRIDE = 1024;  // granules per edge in g_flags (>= workgroups)
 constexpr uint32_t ENG_SPIN_CAP = 1u << 21; // x s_sleep: tens of milliseconds, then give up
 
 enum { ENG_RESIDUAL = 0, ENG_GATEUP = 1, ENG_QKV = 2 };
@@ -72,7 +71,6 @@ struct EngineParams {   // by value in the kernel argument: constant loads the c
     const float *gamma_next; // [E]   attn_norm gain of the next block (op 3), or null
     float eps;
     uint64_t *g_h, *g_act, *g_x;   // granule vectors: E, F, E
-    uint64_t *g_flags;             // [3][ENG_FLAG_STRIDE] per-CU completion flags of the three edges (a hint that spares polling the vectors)
     const uint32_t *epoch;
     // ENG_QKV epilogue
     float *q_out;
@@ -104,8 +102,6 @@ constexpr uint32_t W_XREADY = 4;    // ops whose activation vector is in LDS (mo
 constexpr uint32_t W_DONE = 8;      // stream-wave completions, one per stream wave and op (monotonic)
 constexpr uint32_t W_ARRIVE = 12;   // the control waves' meeting counter (monotonic)
 constexpr uint32_t W_CTL_ISSUED = 16;  // control waves that have REQUESTED their first inputs (the stream waves' weight loads queue behind)
-constexpr uint32_t W_ITEM = 48;      // per op: items of the CU handed out so far (the stream waves draw from it)
-constexpr uint32_t W_FLAGS_OK = 20;  // edges whose per-CU completion flags have all been seen (control wave 0 polls them)
 constexpr uint32_t W_SS = 32;       // per control wave: its share of the sum of squares of the vector being gathered
 
 __device__ __forceinline__ bool eng_give_up(uint32_t *err, uint32_t code)
@@ -186,28 +182,39 @@ __device__ __forceinline__ void eng_publish(uint64_t *g, uint32_t idx, uint32_t 
 // One cursor issues loads two steps ahead of the one that consumes; both are wave-uniform.
 constexpr uint32_t ENG_MAX_UNITS = 64, ENG_MAX_SEG = 4;  // per CU and op (gate|up of Llama-3.1-8B: 56 units); Wdown row segments
 
-// What the issuing side knows about the op it is claiming items from (wave-uniform).
-struct EngClaim {
-    uint32_t oi = 0, nitems = 0, nseg = 1, KC = 1, ub = 0;
+struct EngCursor {
+    uint32_t oi = 0, i = 0, nitems = 0, nseg = 1, KC = 1, ub = 0;
+    uint32_t ul = 0, sub = 0, seg = 0;  // of item i
     bool end = false;
     EngOp o;
 };
-// An item travelling with its register set from issue to consume.
-struct EngItem {
-    uint32_t oi = 0, ul = 0, sub = 0, seg = 0;
-    bool end = true;
-};
 
-template <int U> __device__ __forceinline__ void eng_claim_enter(EngClaim &cl, const EngineParams &p, uint32_t oi)
+template <int U> __device__ __forceinline__ void eng_cursor_item(EngCursor &cu)
 {
-    cl.oi = oi;
-    if (oi >= p.n_ops) { cl.end = true; return; }
-    cl.o = eng_load_op(p.ops, oi);
-    uint32_t ue;
-    eng_unit_range(cl.o.NU, cl.ub, ue);
-    cl.KC = cl.o.K >> 9;
-    cl.nseg = (cl.KC + U - 1) / U;
-    cl.nitems = (ue - cl.ub) * 2 * cl.nseg;
+    const uint32_t q = cu.i / cu.nseg;
+    cu.seg = cu.i - q * cu.nseg;
+    cu.ul = q >> 1;
+    cu.sub = q & 1;
+}
+
+// Enter op `oi` (or the first later op in which this wave owns an item).  `on_skip(op)` is called for every op the wave passes
+// without work (the consuming cursor reports it done).
+template <int U, typename F>
+__device__ __forceinline__ void eng_cursor_enter(EngCursor &cu, const EngineParams &p, uint32_t oi, uint32_t s, F on_skip)
+{
+    for (;; oi++) {
+        if (oi >= p.n_ops) { cu.end = true; cu.oi = oi; return; }
+        cu.o = eng_load_op(p.ops, oi);
+        uint32_t ue;
+        eng_unit_range(cu.o.NU, cu.ub, ue);
+        cu.KC = cu.o.K >> 9;
+        cu.nseg = (cu.KC + U - 1) / U;
+        cu.nitems = (ue - cu.ub) * 2 * cu.nseg;
+        if (s < cu.nitems) break;
+        on_skip(oi);
+    }
+    cu.oi = oi; cu.i = s;
+    eng_cursor_item<U>(cu);
 }
 
 // ONE add per wave (lane 0), the value before it for every lane
@@ -227,53 +234,40 @@ __device__ __forceinline__ void eng_stream(const EngineParams &p, uint8_t *lds, 
     const uint32_t cnt_base = p.cnt_off;                          // [op][unit] arrival counts (zero at launch)
     const uint32_t pos = p.pos ? ((const GLOBAL_AS uint32_t *)p.pos)[0] : 0u;
     STAMP_DECL;  // stream wave: activation of op i seen (2i) | this wave's last item of op i finished (2i + 1)
-    EngClaim cl;
-    eng_claim_enter<U>(cl, p, 0);
-    const GLOBAL_AS uint8_t *last_addr = eng_row(cl.o, cl.ub, 0) + lane * 16;  // a valid address for the surplus loads behind the end
+    EngCursor ic, cc;  // issuing / consuming
+    auto skip_quiet = [](uint32_t) {};
+    auto skip_done = [&](uint32_t) { if (lane == 0) lds_add(W_DONE, 1); };
+    eng_cursor_enter<U>(ic, p, 0, s, skip_quiet);
+    eng_cursor_enter<U>(cc, p, 0, s, skip_done);
+    if (cc.end) return;  // no item in any op (tiny models): the passes above reported every op done
+    const GLOBAL_AS uint8_t *last_addr = eng_row(ic.o, ic.ub, 0) + lane * 16;  // a valid address for the surplus loads behind the end
     // A CU's memory requests are served in order: the control waves' first requests (the vectors op 0 waits for) go ahead of
     // the ~140 KiB of weights this CU's stream waves are about to request (stamps: 7 us -> first FMA otherwise).
     if (!lds_wait_ge(W_CTL_ISSUED, ENG_NCW, p.err, 0x800u)) return;
 
-    // Claim the next item of the CU (the waves of a CU draw from one counter per op: a wave that was held up simply takes fewer),
-    // request its chunks.  Unconditional loads (behind the end of a row / of the sequence: re-reads of the last valid chunk):
-    // every compiler-inserted vmcnt is an exact count.
-    auto issue = [&](u32x4 (&buf)[U], EngItem &it) {
-        it.end = true;
-        while (!cl.end) {
-            const uint32_t i = lds_add_rtn(W_ITEM + cl.oi * 4, 1, lane);
-            if (i < cl.nitems) {
-                const uint32_t q = i / cl.nseg;
-                it.oi = cl.oi; it.seg = i - q * cl.nseg; it.ul = q >> 1; it.sub = q & 1; it.end = false;
-                break;
-            }
-            eng_claim_enter<U>(cl, p, cl.oi + 1);
-        }
-        const uint32_t c0 = it.seg * U;
-        const uint32_t nvalid = it.end ? 1u : min((uint32_t)U, cl.KC - c0);
-        const GLOBAL_AS uint8_t *a = it.end ? last_addr : eng_row(cl.o, cl.ub + it.ul, it.sub) + lane * 16 + (uint64_t)c0 * 1024;
+    // unconditional loads (behind the end of a row / of the sequence: re-reads of the last valid chunk): every
+    // compiler-inserted vmcnt is an exact count
+    auto issue = [&](u32x4 (&buf)[U]) {
+        const uint32_t c0 = ic.seg * U;
+        const uint32_t nvalid = ic.end ? 1u : min((uint32_t)U, ic.KC - c0);
+        const GLOBAL_AS uint8_t *a = ic.end ? last_addr : eng_row(ic.o, ic.ub + ic.ul, ic.sub) + lane * 16 + (uint64_t)c0 * 1024;
 #pragma unroll
         for (int j = 0; j < U; j++) buf[j] = load_nt16((const void *)(a + (uint64_t)min((uint32_t)j, nvalid - 1) * 1024));
         last_addr = a;
-    };
-
-    bool ok = true, finished = false;
-    // the consuming side: the op of the items being multiplied
-    uint32_t c_oi = 0xFFFFFFFFu, c_nseg = 1, c_KC = 1, c_ub = 0;
-    uint32_t done_upto = 0;  // ops [0, done_upto) reported done by this wave
-    EngOp co;
-    const float *xs = XA;
-    auto report_done_upto = [&](uint32_t n) {
-        for (; done_upto < n; done_upto++) {
-#ifdef NFAI_STAMPS
-            if (done_upto == 0) STAMP(1); else if (done_upto == 1) STAMP(3); else if (done_upto == 2) STAMP(5); else STAMP(7);
-#endif
-            if (lane == 0) lds_add(W_DONE, 1);
+        if (!ic.end) {
+            ic.i += ENG_NS;
+            if (ic.i < ic.nitems) eng_cursor_item<U>(ic);
+            else eng_cursor_enter<U>(ic, p, ic.oi + 1, s, skip_quiet);
         }
     };
+
+    bool ok = true;
+    bool fresh_op = true;   // the consuming cursor has not yet checked that its op's activation vector is in LDS
+    const float *xs = XA;
     // the unit's epilogue, by the wave whose item completed it; r0, r1 = the two row sums
     auto finish_unit = [&](float r0, float r1, uint32_t ul) {
-        const EngOp &o = co;
-        const uint32_t u = c_ub + ul;
+        const EngOp &o = cc.o;
+        const uint32_t u = cc.ub + ul;
         if (lane == 0) {
             if (o.mode == ENG_RESIDUAL) {
                 // host residual add of TransformerBlock.cs:153-158 / 176-180: input + projection
@@ -312,32 +306,20 @@ __device__ __forceinline__ void eng_stream(const EngineParams &p, uint8_t *lds, 
             }
         }
     };
-    auto consume = [&](u32x4 (&buf)[U], const EngItem &it) {
-        if (finished || !ok) return;
-        if (it.end) {  // the CU's items are all claimed: this wave has nothing left in any op
-            report_done_upto(p.n_ops);
-            finished = true;
-            return;
-        }
-        if (it.oi != c_oi) {
-            // the first item of an op for this wave: the ops before it are finished as far as this wave is concerned, and the
-            // op's activation vector must be in LDS (the control waves flag it)
-            report_done_upto(it.oi);
-            c_oi = it.oi;
-            co = eng_load_op(p.ops, c_oi);
-            uint32_t ue;
-            eng_unit_range(co.NU, c_ub, ue);
-            c_KC = co.K >> 9;
-            c_nseg = (c_KC + U - 1) / U;
-            ok = lds_wait_ge(W_XREADY, c_oi + 1, p.err, 0x20u);
+    auto consume = [&](u32x4 (&buf)[U]) {
+        if (cc.end || !ok) return;  // surplus loads behind the end of the sequence
+        if (fresh_op) {
+            // the first item of an op: its activation vector must be in LDS (the control waves flag it)
+            ok = lds_wait_ge(W_XREADY, cc.oi + 1, p.err, 0x20u);
             if (!ok) return;
-            xs = co.x_sel ? XB : XA;
+            fresh_op = false;
+            xs = cc.o.x_sel ? XB : XA;
 #ifdef NFAI_STAMPS
-            if (c_oi == 0) STAMP(0); else if (c_oi == 1) STAMP(2); else if (c_oi == 2) STAMP(4); else STAMP(6);
+            if (cc.oi == 0) STAMP(0); else if (cc.oi == 1) STAMP(2); else if (cc.oi == 2) STAMP(4); else STAMP(6);
 #endif
         }
-        const uint32_t c0 = it.seg * U;
-        const uint32_t nvalid = min((uint32_t)U, c_KC - c0);
+        const uint32_t c0 = cc.seg * U;
+        const uint32_t nvalid = min((uint32_t)U, cc.KC - c0);
         const float *xc = xs + (c0 << 9) + (lane << 2);
         float acc = 0.f;
 #pragma unroll
@@ -350,31 +332,41 @@ __device__ __forceinline__ void eng_stream(const EngineParams &p, uint8_t *lds, 
         }
         acc = wave_sum(acc);
         // partial sum of (unit, row, segment) -> LDS; count the item on its unit
-        const uint32_t ubase = c_oi * ENG_MAX_UNITS + it.ul;
-        if (lane == 0) PART[(ubase * 2 + it.sub) * ENG_MAX_SEG + it.seg] = acc;
+        const uint32_t slot = ((cc.oi * ENG_MAX_UNITS + cc.ul) * 2 + cc.sub) * ENG_MAX_SEG + cc.seg;
+        if (lane == 0) PART[slot] = acc;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const uint32_t arrived = lds_add_rtn(cnt_base + ubase * 4, 1, lane);
-        if (arrived + 1 == 2 * c_nseg) {  // this item completed its unit: every partial sum of the unit is in LDS
-            const float *pu = PART + ubase * 2 * ENG_MAX_SEG;
+        const uint32_t arrived = lds_add_rtn(cnt_base + (cc.oi * ENG_MAX_UNITS + cc.ul) * 4, 1, lane);
+        if (arrived + 1 == 2 * cc.nseg) {  // this item completed its unit: every partial sum of the unit is in LDS
+            const float *pu = PART + (cc.oi * ENG_MAX_UNITS + cc.ul) * 2 * ENG_MAX_SEG;
             float r0 = 0.f, r1 = 0.f;
-            for (uint32_t g = 0; g < c_nseg; g++) { r0 += pu[g]; r1 += pu[ENG_MAX_SEG + g]; }  // fixed order
-            finish_unit(r0, r1, it.ul);
+            for (uint32_t g = 0; g < cc.nseg; g++) { r0 += pu[g]; r1 += pu[ENG_MAX_SEG + g]; }  // fixed order
+            finish_unit(r0, r1, cc.ul);
+        }
+        cc.i += ENG_NS;
+        if (cc.i < cc.nitems) {
+            eng_cursor_item<U>(cc);
+        } else {  // that was this wave's last item of the op
+#ifdef NFAI_STAMPS
+            if (cc.oi == 0) STAMP(1); else if (cc.oi == 1) STAMP(3); else if (cc.oi == 2) STAMP(5); else STAMP(7);
+#endif
+            if (lane == 0) lds_add(W_DONE, 1);
+            fresh_op = true;
+            eng_cursor_enter<U>(cc, p, cc.oi + 1, s, skip_done);
         }
     };
 
     // three register sets in rotation, two steps of loads in flight behind the one being multiplied (k_gemv's ping-pong, one deeper)
     u32x4 bufA[U], bufB[U], bufC[U];
-    EngItem itA, itB, itC;
-    issue(bufA, itA);
-    issue(bufB, itB);
-    issue(bufC, itC);
-    while (!finished && ok) {
-        consume(bufA, itA);
-        issue(bufA, itA);
-        consume(bufB, itB);
-        issue(bufB, itB);
-        consume(bufC, itC);
-        issue(bufC, itC);
+    issue(bufA);
+    issue(bufB);
+    issue(bufC);
+    while (!cc.end && ok) {
+        consume(bufA);
+        issue(bufA);
+        consume(bufB);
+        issue(bufB);
+        consume(bufC);
+        issue(bufC);
     }
     STAMP_FLUSH(p.stamps, blockIdx.x * ENG_WAVES + s, 8);
 }
@@ -505,34 +497,6 @@ __device__ __forceinline__ void eng_control(const EngineParams &p, uint8_t *lds,
 #ifdef NFAI_STAMPS
         if (k == 0) STAMP(2); else if (k == 1) STAMP(4); else STAMP(6);
 #endif
-        // Polling the whole vector from every control wave of every CU while other CUs still stream slows exactly those CUs
-        // (MI355X guide, polling-cost).  So: each CU sets ONE flag granule when its outputs of the op are on their way, ONE wave
-        // per CU polls the 2 KiB of flags (with a sleep), and only then the vectors are gathered — normally in one pass.  The
-        // flags are a hint: the gather still checks every tag.
-        if (cw == 0) {
-            uint64_t *flags = p.g_flags + (size_t)k * ENG_FLAG_STRIDE;
-            if (lane == 0) eng_publish(flags, blockIdx.x, epoch, 1.0f);
-            const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void *)flags, 0, (int)(ENG_FLAG_STRIDE * 8), 0x00020000);
-            const uint32_t ncu = gridDim.x;
-            for (uint32_t spins = 0;; spins++) {
-                bool okf = true;
-#pragma unroll
-                for (uint32_t j = 0; j < ENG_FLAG_STRIDE / 128; j++) {
-                    const uint32_t g0 = (j * 64 + lane) * 2;
-                    if (j * 128 < ncu) {  // wave-uniform
-                        const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(fr, (int)(g0 * 8), 0, 16));
-                        okf = okf && (g0 >= ncu || v[1] == epoch) && (g0 + 1 >= ncu || v[3] == epoch);
-                    }
-                }
-                if (__all(okf)) break;
-                if (lds_ld(W_ABORT) != 0) return;
-                if (spins > (ENG_SPIN_CAP >> 5)) { eng_give_up(p.err, 0x1000u); return; }
-                __builtin_amdgcn_s_sleep(16);
-            }
-            lds_st(W_FLAGS_OK, k + 1);
-        } else if (!lds_wait_ge(W_FLAGS_OK, k + 1, p.err, 0x2000u)) {
-            return;
-        }
         bool ok;
         if (k == 0) {         // h = x + Wo.att -> XR (raw: the residual of Wdown), XA = RMSNorm(h) * ffn_norm
             ok = eng_gather<0>(c, p.g_h, p.E, epoch, XR) && c.meet();
@@ -600,8 +564,7 @@ hipError_t engine_plan(const EngineArgs &a, void *params_dev, EnginePlan &plan)
         ops[3].K = E; ops[3].NU = rows / 2; ops[3].mode = ENG_QKV; ops[3].x_sel = 0;
     }
     p.att = a.att; p.x_in = a.x_in; p.gamma_ffn = a.gamma_ffn; p.gamma_next = a.gamma_next; p.eps = a.eps;
-    p.g_h = a.g_h; p.g_act = a.g_act; p.g_x = a.g_x; p.g_flags = a.g_flags; p.epoch = a.epoch;
-    if (!a.g_flags || a.n_cu > ENG_FLAG_STRIDE) return hipErrorInvalidValue;
+    p.g_h = a.g_h; p.g_act = a.g_act; p.g_x = a.g_x; p.epoch = a.epoch;
     p.q_out = a.q_out; p.kc = a.kcache; p.vc = a.vcache; p.kv_pos_stride = a.kv_pos_stride; p.kv_head_stride = a.kv_head_stride;
     p.rope_cs = a.rope_cs; p.rope_dims = a.rope_dims; p.D = a.D; p.pos = a.pos_dev; p.kv_f16 = a.kv_type == NFAI_F16;
     p.err = a.err;

@@ -557,8 +557,8 @@ int build_engine_plans(Model *m)
         e.att = m->att; e.x_in = xin; e.x_out = xout;
         e.gamma_ffn = static_cast<const float *>(L.ffn_norm.ptr);
         e.eps = d.eps;
-        uint64_t *gl = m->d_gran + i * (2 * (size_t)d.E + d.F + ENGINE_FLAG_GRANULES);
-        e.g_h = gl; e.g_act = gl + d.E; e.g_x = gl + d.E + d.F; e.g_flags = gl + 2 * (size_t)d.E + d.F;
+        uint64_t *gl = m->d_gran + i * (2 * (size_t)d.E + d.F);
+        e.g_h = gl; e.g_act = gl + d.E; e.g_x = gl + d.E + d.F;
         e.epoch = m->d_epoch; e.err = m->d_engerr;
         e.n_cu = (uint32_t)m->ctx->prop.multiProcessorCount;
         if (more) {
@@ -650,7 +650,7 @@ NFAI_API int32_t nfai_hip_llama_create(nfai_ctx_t ch, const nfai_llama_desc *des
     DALLOC(m->d_argmax_part, 4096);
     DALLOC(m->d_epoch, 256);
     DALLOC(m->d_engerr, 256);
-    if (m->engine) DALLOC(m->d_gran, (size_t)m->layers.size() * (2 * (size_t)d.E + d.F + ENGINE_FLAG_GRANULES) * 8);
+    if (m->engine) DALLOC(m->d_gran, (size_t)m->layers.size() * (2 * (size_t)d.E + d.F) * 8);
     DALLOC(m->d_attn_part, attn_partials_bytes(d.H, d.Hkv, d.D));
     DALLOC(m->x, d.E * 4);
     DALLOC(m->h, d.E * 4);

@@ -526,7 +526,7 @@ def test_engine_block_op_level(mgr, E, F, H, Hkv, D, with_qkv):
     patt, px, pg1, pg2, pfr = (up(a, np.float32) for a in (att, x, g1, g2, freqs))
     pxo, pq = ShaderProperty(mgr, E), ShaderProperty(mgr, HD)
     pkc, pvc = ShaderProperty(mgr, (pos + 1) * KD), ShaderProperty(mgr, (pos + 1) * KD)
-    nwords = (2 * E + F + 3072) * 2 + 16  # granules of h | act | x, 3 x 1024 completion flags, control words
+    nwords = (2 * E + F) * 2 + 16
     psc = ShaderProperty(mgr, nwords, np.uint32)
     psc.SetValue(np.zeros(nwords, np.uint32))
     def run():
