@@ -1,5 +1,6 @@
-// Drop-in plugin: register BEFORE LlamaModelFactory in Program.cs (Program.cs:16); Parser tries the
-// factories in order and the first TryCreate that returns true wins (Parser.cs:36-42).
+// Drop-in plugin (plugin boundary #2, AbstractModelFactory.TryCreate): register BEFORE LlamaModelFactory in Program.cs
+// (Program.cs:16); Parser tries the factories in order and the first TryCreate that returns true wins (Parser.cs:36-42).
+// NOT compiled in this repository's environment (no .NET SDK in the image).
 using Microsoft.Extensions.AI;
 using NFAI.Core;
 using NFAI.Models;
@@ -8,103 +9,153 @@ using System.Runtime.CompilerServices;
 
 namespace NFAI.HIP;
 
-public sealed class HipBufferManager : IDisposable          // ≙ NFAI.Vulkan.VulkanBufferManager
+/// <summary>≙ LlamaModelFactory (LlamaModelFactory.cs:7-45): owns the device context instead of the Vulkan instance / device.</summary>
+public sealed class HipLlamaModelFactory : AbstractModelFactory
 {
-    internal readonly ulong Ctx;
-    public HipBufferManager(int device = 0) { Native.Check(Native.nfai_hip_ctx_create(device, out Ctx)); }
-    public void Dispose() => Native.Check(Native.nfai_hip_ctx_destroy(Ctx));
-}
+    private readonly HipBufferManager bufferManager;
 
-public sealed class HipLlamaModelFactory : AbstractModelFactory   // ≙ LlamaModelFactory.cs:7-45
-{
-    private readonly HipBufferManager mgr = new();
-    public override void Dispose() => mgr.Dispose();
+    public HipLlamaModelFactory() : this(0) { }
+    public HipLlamaModelFactory(int device) { bufferManager = new HipBufferManager(device); }
 
-    public override bool TryCreate(Dictionary<string, object> metadata, List<AbstractComputeCollection> tensors,
-                                   ModelOptions modelOptions, out IInferenceProvider? model)
+    public override void Dispose()
     {
-        model = null;
-        if ((metadata["general.architecture"].ToString() ?? "") != "llama") return false;
-        // The tensors are lazy views over a stream that Parser.Parse closes on return (Parser.cs:27):
-        // consume them here.  (Raw fp16 bytes are uploaded as-is; AbstractComputeCollection.GetDataRaw
-        // widens fp16 -> fp32, so HipLlamaModel reads the stream range [offset, offset + Length*2) itself.)
-        model = new HipLlamaModel(mgr, metadata, tensors, modelOptions.KVCacheSize);
+        GC.SuppressFinalize(this);
+        bufferManager.Dispose();
+    }
+
+    public override bool TryCreate(Dictionary<string, object> metadata, List<AbstractComputeCollection> tensors, ModelOptions modelOptions,
+                                   out IInferenceProvider? model)
+    {
+        var modelFamily = metadata["general.architecture"].ToString() ?? string.Empty;
+        if (modelFamily != "llama")
+        {
+            model = null;
+            return false;
+        }
+        // The tensors are lazy views over a stream that Parser.Parse closes on return (Parser.cs:27): HipLlamaModel consumes
+        // them all inside its constructor.
+        model = new HipLlamaModel(bufferManager, metadata, tensors, modelOptions.KVCacheSize);
         return true;
     }
 }
 
-public sealed unsafe class HipLlamaModel : IInferenceProvider     // ≙ LlamaModel.cs:10-175
+/// <summary>≙ LlamaModel (LlamaModel.cs:10-175) on libnfai_hip.so's model object: fused kernels, one hipGraph per token, the
+/// whole network resident in HBM with fp16 weights kept fp16.  greedy = true swaps the reference's stochastic TopP for its own
+/// ArgMax (SamplingUtils.cs:43-57), taken on the device with no logits read-back.</summary>
+public sealed unsafe class HipLlamaModel : IInferenceProvider
 {
     private readonly ulong model;
     private readonly Tokenizer tokenizer;
     private readonly float[] logits;
     private bool firstInput = true;
-    public string ModelName { get; init; }
 
-    public HipLlamaModel(HipBufferManager mgr, Dictionary<string, object> md, List<AbstractComputeCollection> tensors, uint contextSize)
+    public string ModelName { get; init; }
+    public bool Greedy { get; set; }
+
+    public HipLlamaModel(HipBufferManager bufferManager, Dictionary<string, object> metadata, List<AbstractComputeCollection> tensors,
+                         uint contextSize = 1024u, LlamaFlags flags = LlamaFlags.None, bool referenceRopeTable = true)
     {
-        ModelName = md["general.name"].ToString() ?? "unknown";
-        tokenizer = new Tokenizer(md);
-        var emb = tensors.First(t => t.Name.Contains("token"));
+        ModelName = metadata["general.name"].ToString() ?? "unknown";
+        tokenizer = new Tokenizer(metadata);                                                   // LlamaModel.cs:41
+        var embed = tensors.FirstOrDefault(x => x.Name.Contains("token")) ?? throw new InvalidOperationException("token_embd.weight not found");
+        var gate = tensors.FirstOrDefault(x => x.Name.Contains("blk.0.ffn_gate")) ?? throw new InvalidOperationException("blk.0.ffn_gate.weight not found");
+        var ropeDimensions = (uint)metadata["llama.rope.dimension_count"];
         var desc = new LlamaDesc
         {
-            E = (uint)emb.Shape[0], V = (uint)emb.Shape[1], L = (uint)md["llama.block_count"],
-            H = (uint)md["llama.attention.head_count"], Hkv = (uint)md["llama.attention.head_count_kv"],
-            D = (uint)md["llama.attention.key_length"],
-            F = (uint)tensors.First(t => t.Name.Contains("blk.0.ffn_gate")).Shape[1],
+            E = (uint)embed.Shape[0], V = (uint)embed.Shape[1],
+            L = (uint)metadata["llama.block_count"],
+            H = (uint)metadata["llama.attention.head_count"],
+            Hkv = (uint)metadata["llama.attention.head_count_kv"],
+            D = (uint)metadata["llama.attention.key_length"],
+            F = (uint)gate.Shape[1],
             C = contextSize,
-            Eps = (float)(md.First(x => x.Key.Contains("epsilon")).Value),            // LlamaModel.cs:28
-            RopeBase = 500000f,                                                        // TransformerBlock.cs:33
-            RopeDims = (uint)md["llama.rope.dimension_count"],
-            RopeNFreqs = Math.Min(32u, (uint)md["llama.rope.dimension_count"] / 2),    // TransformerBlock.cs:66 (reference-exact);
-                                                                                       // use RopeDims/2 for the spec-correct table
-            LayerBegin = 0, LayerEnd = (uint)md["llama.block_count"], Flags = 0, MaxBatch = 0,
+            Eps = (float)(metadata.Where(x => x.Key.Contains("epsilon")).Select(x => x.Value).FirstOrDefault() ?? 0f),   // LlamaModel.cs:28
+            RopeBase = 500000f,                                                                // hard-coded, TransformerBlock.cs:33
+            RopeDims = ropeDimensions,
+            // TransformerBlock.cs:66 uploads 32 frequencies whatever the head size (reference-exact); ropeDimensions / 2 = spec-correct
+            RopeNFreqs = referenceRopeTable ? Math.Min(32u, ropeDimensions / 2) : ropeDimensions / 2,
+            LayerBegin = 0, LayerEnd = (uint)metadata["llama.block_count"],
+            Flags = (uint)flags, MaxBatch = 0,
         };
-        Native.Check(Native.nfai_hip_llama_create(mgr.Ctx, in desc, out model));
-        foreach (var t in tensors)
+        Native.Check(Native.nfai_hip_llama_create(bufferManager.Ctx, in desc, out model));
+        try
         {
-            byte[] raw = RawTensorBytes(t);           // on-disk bytes, NOT GetDataRaw (which widens)
-            fixed (byte* p = raw)
-                Native.Check(Native.nfai_hip_llama_set_tensor(model, t.Name, GgmlTypeOf(t), t.Shape.Length > 1 ? t.Shape[1] : 1,
-                                                              t.Shape[0], p));
+            foreach (var t in tensors)
+            {
+                if (t.Name == "rope_freqs.weight") continue;                                  // ignored by the reference (TransformerBlock.cs:33-38)
+                var raw = TensorBytes.OnDisk(t);                                              // fp16 stays fp16
+                ulong cols = t.Shape[0], rows = t.Shape.Length > 1 ? t.Shape[1] : 1;          // GGUF: ne0 contiguous
+                fixed (byte* p = raw)
+                    Native.Check(Native.nfai_hip_llama_set_tensor(model, t.Name, (int)TensorBytes.TypeOf(t), rows, cols, p));
+            }
+            Native.Check(Native.nfai_hip_llama_finalize(model));
         }
-        Native.Check(Native.nfai_hip_llama_finalize(model));
+        catch
+        {
+            Native.nfai_hip_llama_destroy(model);
+            throw;
+        }
         logits = new float[desc.V];
     }
 
-    public async IAsyncEnumerable<ChatResponseUpdate> GetStreamingResponseAsync(IEnumerable<ChatMessage> messages,
-        ChatOptions? options = null, [EnumeratorCancellation] CancellationToken ct = default)
+    public async IAsyncEnumerable<ChatResponseUpdate> GetStreamingResponseAsync(IEnumerable<ChatMessage> messages, ChatOptions? options = null,
+        [EnumeratorCancellation] CancellationToken cancellationToken = default)
     {
-        var prompt = messages.First(x => x.Role == ChatRole.User).Text;               // LlamaModel.cs:79-80
-        var id = Guid.NewGuid().ToString();
-        await foreach (var part in RunAsync(prompt, ct))
-            yield return new ChatResponseUpdate { ModelId = ModelName, MessageId = id, Contents = [new TextContent(part)] };
+        var messageId = Guid.NewGuid().ToString();
+        var userMessage = messages.FirstOrDefault(x => x.Role == ChatRole.User) ?? throw new ArgumentException("No user message found in the input messages.");
+        var prompt = userMessage.Text;                                                         // LlamaModel.cs:79-80
+        await foreach (var messagePart in RunAsync(prompt, cancellationToken))
+        {
+            yield return new ChatResponseUpdate
+            {
+                CreatedAt = DateTime.UtcNow,
+                ModelId = ModelName,
+                MessageId = messageId,
+                Contents = [new TextContent(messagePart)],
+            };
+        }
     }
 
+    /// <summary>≙ RunAsync (LlamaModel.cs:99-174): the prompt token by token, then sample / feed back until EOS.</summary>
     public async IAsyncEnumerable<string> RunAsync(string prompt, [EnumeratorCancellation] CancellationToken ct = default)
     {
-        var ids = tokenizer.Tokenize(prompt, addBos: firstInput);                     // LlamaModel.cs:101
+        var tokenIds = tokenizer.Tokenize(prompt, addBos: firstInput);                          // :101
         firstInput = false;
-        foreach (var t in ids) Step(t);                                               // :103-126
-        var tk = SamplingUtils.TopP(logits);                                          // :130
+        uint argmax = 0;
+        foreach (var token in tokenIds) argmax = Step(token);                                   // :103-126
+        var tk = Greedy ? argmax : SamplingUtils.TopP(logits);                                  // :128-130
         yield return tokenizer.Detokenize([tk]);
-        while (tk != tokenizer.EosTokenId && !ct.IsCancellationRequested)             // :134-173
+        while (tk != tokenizer.EosTokenId && !ct.IsCancellationRequested)                       // :134-173
         {
-            Step(tk);
-            tk = SamplingUtils.TopP(logits);
+            argmax = Step(tk);
+            tk = Greedy ? argmax : SamplingUtils.TopP(logits);
             if (tk != tokenizer.EosTokenId) yield return tokenizer.Detokenize([tk]);
         }
         await Task.CompletedTask;
     }
 
-    private void Step(uint token)
+    /// <summary>One token through embed → blocks → norm → lm_head (one graph replay); returns the device-side argmax and fills
+    /// `logits` (skipped in greedy mode: 513 KB less per token over PCIe).</summary>
+    private uint Step(uint token)
     {
-        fixed (float* p = logits) Native.Check(Native.nfai_hip_llama_decode_step(model, token, p, out _));
+        uint argmax;
+        if (Greedy)
+        {
+            Native.Check(Native.nfai_hip_llama_decode_step(model, token, null, &argmax));
+        }
+        else
+        {
+            fixed (float* p = logits) Native.Check(Native.nfai_hip_llama_decode_step(model, token, p, &argmax));
+        }
+        return argmax;
     }
 
-    public void Dispose() => Native.Check(Native.nfai_hip_llama_destroy(model));      // the reference throws NotImplementedException (:70-74)
+    /// <summary>New conversation: position 0 (the reference never resets currentToken, TransformerBlock.cs:183).</summary>
+    public void Reset()
+    {
+        Native.Check(Native.nfai_hip_llama_reset(model));
+        firstInput = true;
+    }
 
-    private static int GgmlTypeOf(AbstractComputeCollection t) => t.TypeSize == 2 ? (int)GgmlType.F16 : (int)GgmlType.F32;
-    private static byte[] RawTensorBytes(AbstractComputeCollection t) => throw new NotImplementedException(
-        "read Length*TypeSize bytes at t.offset from the GGUF stream (needs DataStream to be exposed, or re-open ModelOptions.GGUFPath)");
+    public void Dispose() => Native.Check(Native.nfai_hip_llama_destroy(model));               // the reference throws NotImplementedException (:70-74)
 }

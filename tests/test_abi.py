@@ -101,3 +101,75 @@ def test_synth_shapes_match_published_dims():
               for k, v in synth.LLAMA_32_3B.shapes().items() if k.startswith(("token_embd", "blk.0."))}
     d = dims_from_metadata(md, shapes)
     assert (d["E"], d["L"], d["H"], d["Hkv"], d["D"], d["F"], d["V"]) == (3072, 28, 24, 8, 128, 8192, 128256)
+
+
+# ---- the C# binding (csharp/NFAI.HIP): cannot be compiled here (no .NET SDK), so its consistency with the C ABI is checked as text ----
+def _split_args(s):
+    """top-level comma split of a C# / C argument list"""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([<{":
+            depth += 1
+        elif ch in ")]>}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _csharp_decls():
+    src = open(os.path.join(ROOT, "csharp", "NFAI.HIP", "NativeMethods.g.cs")).read()
+    return {m.group(1): _split_args(m.group(2)) for m in re.finditer(r"internal static partial \w+ (nfai_hip_\w+)\((.*?)\);", src)}
+
+
+def test_csharp_declarations_match_the_header():
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_csharp_bindings as gen
+    assert subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_csharp_bindings.py"), "--check"]).returncode == 0
+    decls = _csharp_decls()
+    header = {name: params for name, _, params in gen.parse_header()}
+    assert set(decls) == set(header) == set(header_functions())
+    for name, params in header.items():
+        assert len(decls[name]) == len(params), name
+
+
+def test_csharp_sources_call_declared_entry_points_and_have_no_stubs():
+    decls = _csharp_decls()
+    cs_dir = os.path.join(ROOT, "csharp", "NFAI.HIP")
+    files = [f for f in os.listdir(cs_dir) if f.endswith(".cs") and f != "NativeMethods.g.cs"]
+    assert {"HipBufferManager.cs", "HipShaderProperty.cs", "HipShaders.cs", "HipLlamaModelFactory.cs", "HipPipeline.cs", "Native.cs"} <= set(files)
+    called = set()
+    for f in files:
+        src = open(os.path.join(cs_dir, f)).read()
+        code = re.sub(r"//[^\n]*", "", src)
+        assert "NotImplementedException" not in code, f  # only the reference throws it (LlamaModel.cs:70-74)
+        for m in re.finditer(r"Native\.(nfai_hip_\w+)\(", code):
+            name, i, depth = m.group(1), m.end(), 1
+            while depth:  # matching parenthesis of the call
+                depth += {"(": 1, ")": -1}.get(code[i], 0)
+                i += 1
+            args = _split_args(code[m.end():i - 1])
+            assert name in decls, (f, name)
+            assert len(args) == len(decls[name]), (f, name, args)
+            called.add(name)
+    # the operator surface (ten op classes + block), buffers, model, pipeline are all bound to something real
+    for need in ("nfai_hip_embed", "nfai_hip_rmsnorm", "nfai_hip_gemv", "nfai_hip_rope", "nfai_hip_attn_scores", "nfai_hip_attn_softmax",
+                 "nfai_hip_attn_wsum", "nfai_hip_silu", "nfai_hip_mul", "nfai_hip_add", "nfai_hip_buf_alloc", "nfai_hip_buf_upload",
+                 "nfai_hip_buf_download", "nfai_hip_buf_copy", "nfai_hip_weight_upload", "nfai_hip_llama_create", "nfai_hip_llama_set_tensor",
+                 "nfai_hip_llama_finalize", "nfai_hip_llama_decode_step", "nfai_hip_pp_init", "nfai_hip_pp_send_hidden"):
+        assert need in called, need
+    shaders = open(os.path.join(cs_dir, "HipShaders.cs")).read()
+    for cls in ("HipTokenEmbedShader", "HipRMSNormShader", "HipMatrixMultiplyShader", "HipRoPEShader", "HipAttentionScoreCalculationShader",
+                "HipAttentionSoftmaxShader", "HipAttentionWeightedValueSumShader", "HipSiLUShader", "HipElementWiseMultiplicationShader",
+                "HipTransformerBlock"):
+        assert f"class {cls}" in shaders, cls
+    prop = open(os.path.join(cs_dir, "HipShaderProperty.cs")).read()
+    for member in ("BindShaderProprty", "SetValue", "GetValue", "TransferTo", "Count"):  # ShaderProperty.cs:20-182
+        assert member in prop, member
