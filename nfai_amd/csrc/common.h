@@ -166,8 +166,15 @@ struct AttnArgs {
     float *o = nullptr;        // [H][D]
     uint32_t H = 0, Hkv = 0, D = 0, C = 0;
     const uint32_t *pos_dev = nullptr;  // S = *pos_dev + 1
-    float *partials = nullptr;          // workspace: [Hkv][NSPLIT_MAX][G*(D+2)]
+    float *partials = nullptr;          // workspace: attn_partials_bytes()
     uint32_t n_cu = 256;
+    // Slice hand-off.  epoch == nullptr: ticket form (partials written through, one ticket per block, the last block of a kv head
+    // merges).  epoch != nullptr: granule form — every partial word travels as an 8-byte {value, tag} granule and the block of
+    // the LAST slice polls the granules themselves; tag = epoch[0] * tag_mul + tag_add must differ from the tag of every earlier
+    // launch that used this workspace (the model: per-token epoch x blocks + block index).  A poll that gives up sets *err.
+    const uint32_t *epoch = nullptr;
+    uint32_t tag_mul = 1, tag_add = 0;
+    uint32_t *err = nullptr;
 };
 constexpr uint32_t ATTN_NSPLIT_MAX = 32;
 size_t attn_partials_bytes(uint32_t H, uint32_t Hkv, uint32_t D);

@@ -352,6 +352,8 @@ int submit_attn(Model *m, Layer &L, Sched &sch)
     a.o = m->att; a.H = d.H; a.Hkv = d.Hkv; a.D = d.D; a.C = d.C;
     a.pos_dev = m->d_pos; a.partials = m->d_attn_part;
     a.n_cu = (uint32_t)m->ctx->prop.multiProcessorCount;
+    // slice hand-off by {value, tag} granules: tag = token epoch x blocks + block (never the tag of an earlier launch on this workspace)
+    a.epoch = m->d_epoch; a.tag_mul = (uint32_t)m->layers.size() + 1; a.tag_add = (uint32_t)(&L - m->layers.data()) + 1; a.err = m->d_engerr;
     return sch.submit(op_attn(KC_ATTN, a));
 }
 
@@ -582,13 +584,16 @@ int build_engine_plans(Model *m)
 
 uint64_t tensor_bytes(const Tensor &t) { return t.ptr ? weight_row_bytes(t.type, t.cols) * t.rows : 0; }
 
-// A bounded wait inside an engine launch gave up (a workgroup was not resident, or a producer never published): the
-// results of that token are not valid.  The word is sticky until the model is reset.
+// A bounded wait inside a launch gave up (a workgroup was not resident, or a producer never published): the results of that
+// token are not valid.  The word is sticky until the model is reset.
 int engine_failed(Model *m, uint32_t code)
 {
+    if (code == 0x1000u)
+        return fail(NFAI_ERR_HIP, "attention launch gave up waiting for the partial results of a KV slice (code 0x1000): are all its "
+                                  "workgroups resident?  NFAI_ATTN_POLL=0 selects the ticket hand-off");
     return fail(NFAI_ERR_HIP, "engine launch gave up waiting (code 0x%x: 0x10 ring slot, 0x20 activation, 0x40 weights, 0x80 gather, "
-                              "0x100-0x400 consumers): are all %d workgroups resident?  NFAI_ENGINE=0 selects the five-launch path",
-                code, m->ctx->prop.multiProcessorCount);
+                              "0x100-0x400 consumers, 0x1000 attention slices): are all %d workgroups resident?  NFAI_ENGINE=0 selects "
+                              "the five-launch path", code, m->ctx->prop.multiProcessorCount);
 }
 
 }  // namespace

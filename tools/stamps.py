@@ -131,10 +131,16 @@ def main():
             d["scores"].extend(t[:, 2] - t[:, 0])
             d["softmax"].extend(t[:, 3] - t[:, 2])
             d["v_and_partials"].extend(t[:, 4] - t[:, 3])
-            d["partials_acked"].extend(t[:, 5] - t[:, 4])
-            d["ticket"].extend(t[:, 6] - t[:, 5])
             mg = t[t[:, 7] > 0]
-            d["merge"].extend(mg[:, 7] - mg[:, 6])
+            if (t[:, 6] > 0).any():   # ticket hand-off (NFAI_ATTN_POLL=0)
+                d["partials_acked"].extend(t[:, 5] - t[:, 4])
+                d["ticket"].extend(t[:, 6] - t[:, 5])
+                d["merge"].extend(mg[:, 7] - mg[:, 6])
+            else:                     # granule hand-off: only the block of the last slice goes on after stamp 4
+                d.setdefault("merger_own_slice_done", []).extend(mg[:, 4] - L["t0"])
+                d.setdefault("slowest_producer_published", []).append(float(t[t[:, 7] == 0][:, 4].max() - L["t0"]) if (t[:, 7] == 0).any() else 0.0)
+                d.setdefault("granules_seen_after_own_slice", []).extend(mg[:, 5] - mg[:, 4])
+                d.setdefault("merge_and_store", []).extend(mg[:, 7] - mg[:, 5])
         else:
             d["issued"].extend(t[:, 1] - t[:, 0])
             d["x_ready"].extend(t[:, 2] - t[:, 0])
