@@ -534,24 +534,36 @@ hipError_t launch_gemm_kq(const GemmArgs &a, hipStream_t s)
 // would drain the DMAs (its fence waits vmcnt(0)), hence the raw barrier + counted waits (MI355X guide, §5).
 template <int N> __device__ __forceinline__ void wait_vmcnt()
 {
-    static_assert(N == 0 || N == 6 || N == 8 || N == 12 || N == 16, "add the literal");
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit count");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
 
 // PIPE: the fragments of k-step s+1 are read from LDS while the MFMAs of step s run (double-buffered registers, issue order
 // pinned with sched_group_barrier).  Left alone hipcc reads a whole step, waits lgkmcnt(0) and then issues its MFMAs: with one
 // wave per SIMD (the narrow GEMMs: one workgroup per CU) every step then exposes a full LDS latency.
-template <int BM, int BN, int WM, int WN, int EPI, int NST, int BK = 64, bool PIPE = false>
+// NSTB > NST ("roles"): the B operand (the weights: cold, read once from HBM) gets a deeper ring than the A operand (the
+// activations: L2 hits), NSTB - 1 weight tiles in flight per workgroup.  vmcnt retires in issue order PER WAVE, so a wave that
+// issued both operands would wait for its far-ahead weight tiles whenever it waits for the next activation tile: waves 0-1 issue
+// only A, waves 2-3 only B, each with its own counted wait; the barrier joins them.  (In a prefill the 192-workgroup
+// projections were found waiting on HBM latency, not on L2 / LDS / MFMA: profiles/round2_prefill_pmc.json — 1 TB/s on the
+// memory side, MFMA 22 % busy.)
+template <int BM, int BN, int WM, int WN, int EPI, int NST, int BK = 64, bool PIPE = false, int NSTB = NST>
 __global__ __launch_bounds__(256) void k_gemm_f16_glds(const GemmParams p)
 {
+    static_assert(NSTB >= NST, "the weight ring is at least as deep as the activation ring");
     static_assert(WM * WN == 4, "four waves");
+    constexpr bool ROLES = NSTB != NST;
     constexpr int CH = BK / 8, RPI = 64 / CH, TM = BM / WM / 16, TN = BN / WN / 16;  // RPI = tile rows per LDS-DMA instruction
-    constexpr int AG = BM / RPI / 4, BG = BN / RPI / 4;  // LDS-DMA instructions per wave and tile
-    constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
+    // LDS-DMA instructions per wave and tile.  Without roles the tile's BM / RPI + BN / RPI instructions are dealt to the four
+    // waves round-robin; when BN / RPI is not a multiple of four (BN = 80, 48: tile widths that give exactly 256 workgroups on the
+    // 5120- and 3072-column projections at 512 rows) the last B instruction exists only for the first waves (b_last).  With roles
+    // a wave pair shares one operand: instruction i of pair member w covers LDS rows (i * 2 + w) * RPI ...
+    constexpr int NAI = BM / RPI, NBI = BN / RPI;
+    constexpr int AG = ROLES ? NAI / 2 : NAI / 4, BG = ROLES ? NBI / 2 : (NBI + 3) / 4;
+    constexpr int DEAL = ROLES ? 2 : 4;
+    constexpr bool B_EVEN = ROLES || NBI % 4 == 0;
+    static_assert(BM % (RPI * 4) == 0 && BN % RPI == 0 && (!ROLES || NBI % 2 == 0), "tile rows per LDS-DMA instruction");
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, B_BASE = NST * A_BYTES;  // LDS: NST A stages, then NSTB B stages
     static_assert(EPI != EPI_SILU || BN / WN == 64, "SiLU epilogue pairs columns inside a 64-wide wave slice");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     typedef __attribute__((address_space(3))) uint8_t lds_u8;
@@ -574,42 +586,49 @@ __global__ __launch_bounds__(256) void k_gemm_f16_glds(const GemmParams p)
     const uint32_t m0 = mt_i * BM, n0 = nt_i * BN, batch = blockIdx.y;
     if (p.causal == 1 && n0 > p.causal_pos0 + m0 + BM - 1) return;
     const GLOBAL_AS uint8_t *Ab = (const GLOBAL_AS uint8_t *)(p.A + (uint64_t)batch * p.a_bs);
-    const uint32_t seg = n0 < p.seg_end[0] ? 0u : (n0 < p.seg_end[1] ? 1u : 2u);
-    const uint32_t nrow0 = n0 - (seg == 0 ? 0u : p.seg_end[seg - 1]);
-    const GLOBAL_AS uint8_t *Bb = (const GLOBAL_AS uint8_t *)(p.B[seg] + (uint64_t)(batch / p.b_div) * p.b_bs);
     const GLOBAL_AS uint8_t *Bg = (const GLOBAL_AS uint8_t *)p.B[0], *Bu = (const GLOBAL_AS uint8_t *)p.B[1];
+    const bool role_a = !ROLES || wave < 2, role_b = !ROLES || wave >= 2;  // wave-uniform
+    const uint32_t dw = ROLES ? (wave & 1) : wave;                         // this wave's place in the deal
+    const bool b_last = B_EVEN || (uint32_t)(BG - 1) * 4 + wave < (uint32_t)NBI;
 
-    // per-lane source rows: instruction i of this wave covers LDS rows (i*4 + wave)*RPI .. +RPI-1, lane = (row % RPI) * CH + c'
+    // per-lane source rows: lane = (row % RPI) * CH + c'
     const uint32_t lrow = lane / CH, lc = lane % CH;
     static_assert(AG <= 8 && BG <= 8, "source pointer arrays");
     const GLOBAL_AS uint8_t *asrc[8], *bsrc[8];  // fixed bounds: with [AG] / [BG] the host pass of hipcc 7.2 silently drops the kernel's definition
 #pragma unroll
     for (int i = 0; i < AG; i++) {
-        const uint32_t row = (i * 4 + wave) * RPI + lrow;
+        const uint32_t row = (i * DEAL + dw) * RPI + lrow;
         asrc[i] = Ab + ((uint64_t)min(m0 + row, p.M - 1) * p.lda + (lc ^ (row & (CH - 1))) * 8) * 2;
     }
 #pragma unroll
     for (int i = 0; i < BG; i++) {
-        const uint32_t row = (i * 4 + wave) * RPI + lrow;
+        const uint32_t row = min((i * DEAL + dw) * RPI + lrow, (uint32_t)BN - 1);
         const uint32_t chunk = lc ^ (row & (CH - 1));
         if constexpr (EPI == EPI_SILU) {
             const uint32_t sl = row >> 6, cc = row & 63, out = n0 / 2 + sl * 32 + (cc & 31);
             bsrc[i] = (cc < 32 ? Bg : Bu) + ((uint64_t)out * p.ldb + chunk * 8) * 2;
         } else {
-            bsrc[i] = Bb + ((uint64_t)(nrow0 + row) * p.ldb + chunk * 8) * 2;
+            // the row's segment (q | k | v are three tensors): per row, so a tile may straddle a segment boundary
+            const uint32_t n = n0 + row;
+            const uint32_t seg = n < p.seg_end[0] ? 0u : (n < p.seg_end[1] ? 1u : 2u);
+            const uint32_t nrow = n - (seg == 0 ? 0u : p.seg_end[seg - 1]);
+            bsrc[i] = (const GLOBAL_AS uint8_t *)(p.B[seg] + (uint64_t)(batch / p.b_div) * p.b_bs) + ((uint64_t)nrow * p.ldb + chunk * 8) * 2;
         }
     }
-    auto issue_tile = [&](uint32_t kt, uint32_t stage) {
+    auto issue_a = [&](uint32_t kt, uint32_t stage) {
         const uint32_t koff = kt * (BK * 2);
 #pragma unroll
         for (int i = 0; i < AG; i++) {
-            lds_u8 *da = (lds_u8 *)(lds + stage * STAGE + (i * 4 + wave) * 1024);
+            lds_u8 *da = (lds_u8 *)(lds + stage * A_BYTES + (i * DEAL + dw) * 1024);
             __builtin_amdgcn_global_load_lds(asrc[i] + koff, da, 16, 0, 0);
         }
+    };
+    auto issue_b = [&](uint32_t kt, uint32_t stage) {
+        const uint32_t koff = kt * (BK * 2);
 #pragma unroll
         for (int i = 0; i < BG; i++) {
-            lds_u8 *db = (lds_u8 *)(lds + stage * STAGE + A_BYTES + (i * 4 + wave) * 1024);
-            __builtin_amdgcn_global_load_lds(bsrc[i] + koff, db, 16, 0, 0);
+            lds_u8 *db = (lds_u8 *)(lds + B_BASE + stage * B_BYTES + (i * DEAL + dw) * 1024);
+            if (B_EVEN || i < BG - 1 || b_last) __builtin_amdgcn_global_load_lds(bsrc[i] + koff, db, 16, 0, 0);
         }
     };
 
@@ -621,15 +640,37 @@ __global__ __launch_bounds__(256) void k_gemm_f16_glds(const GemmParams p)
 
     uint32_t KT = p.K / BK;
     if (p.causal == 2) KT = min(KT, (p.causal_pos0 + m0 + BM + BK - 1) / BK);
+    // prologue: tiles 0 .. depth-2 of each ring (past the end: the last tile again — the counts stay uniform)
+    if constexpr (ROLES) {
+        if (role_a) {
 #pragma unroll
-    for (int s = 0; s < NST - 1; s++) issue_tile(min((uint32_t)s, KT - 1), s);
+            for (int s2 = 0; s2 < NST - 1; s2++) issue_a(min((uint32_t)s2, KT - 1), s2);
+        } else {
+#pragma unroll
+            for (int s2 = 0; s2 < NSTB - 1; s2++) issue_b(min((uint32_t)s2, KT - 1), s2);
+        }
+    } else {
+#pragma unroll
+        for (int s2 = 0; s2 < NST - 1; s2++) {
+            issue_a(min((uint32_t)s2, KT - 1), s2);
+            issue_b(min((uint32_t)s2, KT - 1), s2);
+        }
+    }
 
-    uint32_t cur = 0, fill = NST - 1;  // stage being multiplied, stage being refilled
+    uint32_t cur = 0, fill = NST - 1;     // A: stage being multiplied, stage being refilled
+    uint32_t curb = 0, fillb = NSTB - 1;  // B likewise
     for (uint32_t kt = 0; kt < KT; kt++) {
-        wait_vmcnt<(AG + BG) * (NST - 2)>();
+        if constexpr (ROLES) {
+            if (role_a) wait_vmcnt<AG * (NST - 2)>();
+            else wait_vmcnt<BG * (NSTB - 2)>();
+        } else {
+            if (b_last) wait_vmcnt<(AG + BG) * (NST - 2)>();
+            else wait_vmcnt<(AG + BG - 1) * (NST - 2)>();
+        }
         __builtin_amdgcn_s_barrier();
-        issue_tile(min(kt + NST - 1, KT - 1), fill);
-        const uint8_t *la = lds + cur * STAGE, *lb = la + A_BYTES;
+        if (role_a) issue_a(min(kt + NST - 1, KT - 1), fill);
+        if (role_b) issue_b(min(kt + NSTB - 1, KT - 1), fillb);
+        const uint8_t *la = lds + cur * A_BYTES, *lb = lds + B_BASE + curb * B_BYTES;
         constexpr int KSTEPS = BK / 32;
         auto load_frags = [&](int ks, f16x8 (&a)[TM], f16x8 (&b)[TN]) {
             const uint32_t chunk = ks * 4 + (lane >> 4);
@@ -678,17 +719,20 @@ __global__ __launch_bounds__(256) void k_gemm_f16_glds(const GemmParams p)
         }
         cur = cur + 1 == NST ? 0 : cur + 1;
         fill = fill + 1 == NST ? 0 : fill + 1;
+        curb = curb + 1 == NSTB ? 0 : curb + 1;
+        fillb = fillb + 1 == NSTB ? 0 : fillb + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus DMAs of the last iterations must not outlive the workgroup's LDS
     gemm_store<BM, BN, WM, WN, EPI, TM, TN>(acc, p, m0, n0, wm, wn, lane, batch);
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int NST, int BK = 64, bool PIPE = false>
+template <int BM, int BN, int WM, int WN, int EPI, int NST, int BK = 64, bool PIPE = false, int NSTB = NST>
 static hipError_t gemm_launch_glds(const GemmParams &p, uint32_t batch, hipStream_t s)
 {
-    constexpr int LDS = NST * (BM + BN) * BK * 2;
+    constexpr int LDS = (NST * BM + NSTB * BN) * BK * 2;
+    static_assert(LDS <= 160 * 1024, "LDS of one CU");
     if (p.K % BK) return hipErrorInvalidValue;
-    auto kern = k_gemm_f16_glds<BM, BN, WM, WN, EPI, NST, BK, PIPE>;
+    auto kern = k_gemm_f16_glds<BM, BN, WM, WN, EPI, NST, BK, PIPE, NSTB>;
     static bool attr_set = false;
     if (LDS > 64 * 1024 && !attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -722,7 +766,8 @@ template <int EPI>
 static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int variant, hipStream_t s)
 {
     if (variant) {  // explicit configuration (tests, tools)
-        if (((variant >= 2 && variant <= 4) || variant == 11) && p.N % 128 != 0) return hipErrorInvalidValue;
+        if (((variant >= 2 && variant <= 4) || variant == 11 || variant == 18 || variant == 19) && p.N % 128 != 0) return hipErrorInvalidValue;
+        if (variant >= 12 && variant <= 15 && (p.seg_end[0] % 16 || p.seg_end[1] % 16)) return hipErrorInvalidValue;
         switch (variant) {
             case 1: return gemm_launch<128, 64, 4, 1, 64, EPI>(p, batch, s);
             case 2: return gemm_launch<128, 128, 2, 2, 64, EPI>(p, batch, s);
@@ -735,6 +780,15 @@ static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int va
             case 9: return gemm_launch_glds<128, 64, 4, 1, EPI, 3, 128, true>(p, batch, s);   // BK 128, 3 stages (144 KB)
             case 10: return gemm_launch_glds<128, 64, 4, 1, EPI, 2, 128, true>(p, batch, s);  // BK 128, 2 stages
             case 11: return gemm_launch_glds<128, 128, 2, 2, EPI, 2, 64, true>(p, batch, s);
+            case 12: if constexpr (EPI != EPI_SILU) return p.N % 80 ? hipErrorInvalidValue : gemm_launch_glds<128, 80, 4, 1, EPI, 3>(p, batch, s); else break;
+            case 13: if constexpr (EPI != EPI_SILU) return p.N % 48 ? hipErrorInvalidValue : gemm_launch_glds<128, 48, 4, 1, EPI, 3>(p, batch, s); else break;
+            case 14: if constexpr (EPI != EPI_SILU) return p.N % 80 ? hipErrorInvalidValue : gemm_launch_glds<128, 80, 4, 1, EPI, 4>(p, batch, s); else break;
+            case 15: if constexpr (EPI != EPI_SILU) return p.N % 48 ? hipErrorInvalidValue : gemm_launch_glds<128, 48, 4, 1, EPI, 4>(p, batch, s); else break;
+            case 16: return gemm_launch_glds<128, 64, 4, 1, EPI, 3, 64, false, 6>(p, batch, s);    // weights 5 tiles ahead (96 KB)
+            case 17: return gemm_launch_glds<128, 64, 4, 1, EPI, 3, 64, false, 9>(p, batch, s);    // weights 8 tiles ahead (120 KB)
+            case 18: return gemm_launch_glds<128, 128, 2, 2, EPI, 3, 64, false, 4>(p, batch, s);   // 128 x 128: weights 3 tiles ahead (112 KB)
+            case 19: return gemm_launch_glds<128, 128, 2, 2, EPI, 3, 64, false, 6>(p, batch, s);   // 5 tiles ahead (144 KB)
+            case 20: if constexpr (EPI != EPI_SILU) return p.N % 80 ? hipErrorInvalidValue : gemm_launch_glds<128, 80, 4, 1, EPI, 3, 64, false, 6>(p, batch, s); else break;
         }
         return hipErrorInvalidValue;
     }
@@ -784,6 +838,26 @@ static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int va
     // narrow N (192-320 workgroups of 128 x 64): direct-to-LDS with 3 stages (72 KB).  Measured end to end, three runs
     // each: 7.06 ms against 7.18 ms register-staged; 2 stages 8.27 ms, 4 stages 7.42 ms.  0 = register staging.
     static const int env_glds_n = getenv("NFAI_GEMM_GLDS_NARROW") ? atoi(getenv("NFAI_GEMM_GLDS_NARROW")) : 3;
+    // Tile width of the narrow configuration: the one that needs the fewest rounds of workgroups over the CUs, then the fewest
+    // operand bytes per workgroup (cost = rounds x (BM + BN)).  At 512 rows: N = 5120 (q|k|v of 3B) -> 80 (256 workgroups instead
+    // of 320 = 1.25 rounds: 43.2 -> 28.9 us with cold weights), N = 3072 -> 48 (256 instead of 192: 27.2 -> 24.0 us, K = 8192:
+    // 64.5 -> 56.6 us), N = 6144 (q|k|v of 8B) -> 96.  tools/gemm_bench.py --cold; NFAI_GEMM_BN=64 keeps the fixed width.
+    static const int env_bn = getenv("NFAI_GEMM_BN") ? atoi(getenv("NFAI_GEMM_BN")) : 0;
+    if constexpr (EPI != EPI_SILU) {
+        if (env_glds_n == 3 && p.ksplit == 1 && batch == 1 && p.causal == 0 && env_bn != 64) {
+            const uint64_t tm = (p.M + 127) / 128;
+            auto cost = [&](uint32_t bn) { return ((tm * (p.N / bn) + n_cu - 1) / n_cu) * (128 + bn); };
+            uint32_t best = 64;
+            uint64_t best_cost = cost(64);
+            for (uint32_t bn : {48u, 80u, 96u}) {
+                if (env_bn && (uint32_t)env_bn != bn) continue;
+                if (p.N % bn == 0 && cost(bn) * 100 < best_cost * 97) { best = bn; best_cost = cost(bn); }
+            }
+            if (best == 48) return gemm_launch_glds<128, 48, 4, 1, EPI, 3>(p, batch, s);
+            if (best == 80) return gemm_launch_glds<128, 80, 4, 1, EPI, 3>(p, batch, s);
+            if (best == 96) return gemm_launch_glds<128, 96, 4, 1, EPI, 3>(p, batch, s);
+        }
+    }
     if (env_glds_n == 2 && p.ksplit == 1) return gemm_launch_glds<128, 64, 4, 1, EPI, 2>(p, batch, s);
     if (env_glds_n == 3 && p.ksplit == 1) return gemm_launch_glds<128, 64, 4, 1, EPI, 3>(p, batch, s);
     if (env_glds_n == 4 && p.ksplit == 1) return gemm_launch_glds<128, 64, 4, 1, EPI, 4>(p, batch, s);

@@ -364,8 +364,9 @@ def test_error_paths(mgr):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11],
-                         ids=["auto", "128x64", "128x128", "glds2", "glds3", "glds-n2", "glds-n3", "glds-n4", "glds-n3-pipe", "glds-n3-bk128", "glds-n2-bk128", "glds2-pipe"])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19],
+                         ids=["auto", "128x64", "128x128", "glds2", "glds3", "glds-n2", "glds-n3", "glds-n4", "glds-n3-pipe", "glds-n3-bk128", "glds-n2-bk128", "glds2-pipe",
+                              "roles-n-b6", "roles-n-b9", "roles-w-b4", "roles-w-b6"])
 @pytest.mark.parametrize("M,N,K,res", [(512, 1024, 512, True), (200, 256, 384, False), (128, 384, 3072, True)])
 def test_gemm_f16_variants(mgr, variant, M, N, K, res):
     """The prefill GEMM (MatrixMultiplyShader with inputRowCount = M, which the reference never exercises) in every tile /
@@ -391,12 +392,38 @@ def test_gemm_f16_variants(mgr, variant, M, N, K, res):
     assert np.abs(got - want).max() <= 2e-6 * np.sqrt(K) * scale + 1e-5, np.abs(got - want).max()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [12, 13, 14, 15, 20], ids=["128x80-glds3", "128x48-glds3", "128x80-glds4", "128x48-glds4", "128x80-roles-b6"])
+@pytest.mark.parametrize("M,N,K,res", [(512, 960, 512, True), (200, 960, 384, False), (512, 5760, 3072, True)])
+def test_gemm_f16_odd_tile_widths(mgr, variant, M, N, K, res):
+    """Tile widths 80 and 48 (exactly 256 workgroups on the 5120- and 3072-column projections at 512 rows): the B tile's
+    LDS-DMA instructions do not divide evenly over the four waves, so the waves wait on different counts."""
+    from nfai_amd._lib import call
+    from nfai_amd.hip import ShaderProperty
+    r = np.random.Generator(np.random.PCG64(100 * variant + M))
+    A = r.standard_normal((M, K)).astype(np.float16)
+    W = (0.05 * r.standard_normal((N, K))).astype(np.float16)
+    R = r.standard_normal((M, N)).astype(np.float32) if res else None
+    pa, pw = ShaderProperty(mgr, M * K, np.float16), ShaderProperty(mgr, N * K, np.float16)
+    pc = ShaderProperty(mgr, M * N, np.float32)
+    pa.SetValue(A.ravel()); pw.SetValue(W.ravel())
+    pr = None
+    if res:
+        pr = ShaderProperty(mgr, M * N, np.float32)
+        pr.SetValue(R.ravel())
+    call("nfai_hip_gemm_f16", mgr.handle, pa.handle, pw.handle, pr.handle if res else 0, pc.handle, M, N, K, variant)
+    got = pc.GetValue().reshape(M, N)
+    want = A.astype(np.float64) @ W.astype(np.float64).T + (R.astype(np.float64) if res else 0.0)
+    scale = float(np.abs(A.astype(np.float64)).mean() * np.abs(W.astype(np.float64)).mean() * K)
+    assert np.abs(got - want).max() <= 2e-6 * np.sqrt(K) * scale + 1e-5, np.abs(got - want).max()
+
+
 def _silu64(x):
     return x / (1.0 + np.exp(-x))
 
 
-WIDE = [0, 2, 3, 4, 11]     # 128 x 128 tile configurations (what gemm_pick takes for wide N at prefill sizes)
-NARROW = [1, 5, 6, 7, 8]    # 128 x 64
+WIDE = [0, 2, 3, 4, 11, 18, 19]     # 128 x 128 tile configurations (what gemm_pick takes for wide N at prefill sizes)
+NARROW = [1, 5, 6, 7, 8, 16, 17]    # 128 x 64
 
 
 @pytest.mark.gpu

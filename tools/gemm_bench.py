@@ -10,30 +10,42 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nfai_amd._lib import call  # noqa: E402
 from nfai_amd.hip import HipBufferManager, ShaderProperty  # noqa: E402
 
-NAMES = {0: "auto", 1: "128x64 reg", 2: "128x128 reg", 3: "128x128 glds2", 4: "128x128 glds3", 5: "128x64 glds2", 6: "128x64 glds3", 7: "128x64 glds4", 8: "128x64 glds3 pipe", 9: "128x64 glds3 bk128 pipe", 10: "128x64 glds2 bk128 pipe", 11: "128x128 glds2 pipe"}
+NAMES = {0: "auto", 1: "128x64 reg", 2: "128x128 reg", 3: "128x128 glds2", 4: "128x128 glds3", 5: "128x64 glds2", 6: "128x64 glds3", 7: "128x64 glds4", 8: "128x64 glds3 pipe", 9: "128x64 glds3 bk128 pipe", 10: "128x64 glds2 bk128 pipe", 11: "128x128 glds2 pipe", 12: "128x80 glds3", 13: "128x48 glds3", 14: "128x80 glds4", 15: "128x48 glds4", 16: "128x64 roles a3 b6", 17: "128x64 roles a3 b9", 18: "128x128 roles a3 b4", 19: "128x128 roles a3 b6", 20: "128x80 roles a3 b6"}
 
 
 def main():
-    T = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    """--cold: every call reads a different copy of the weights (640 MB of copies per shape: beyond the 256 MB Infinity Cache), as
+    in a prefill, where a projection's weights are touched once per 512 tokens; without it the 20 calls re-read one matrix that
+    stays in the Infinity Cache."""
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    cold = "--cold" in sys.argv
+    T = int(args[0]) if args else 512
     mgr = HipBufferManager(0)
     for (N, K) in ((5120, 3072), (3072, 3072), (16384, 3072), (3072, 8192)):
-        pa, pw = ShaderProperty(mgr, T * K, np.float16), ShaderProperty(mgr, N * K, np.float16)
+        nw = max(2, -(-640 * 2**20 // (N * K * 2))) if cold else 1
+        pa = ShaderProperty(mgr, T * K, np.float16)
+        pws = [ShaderProperty(mgr, N * K, np.float16) for _ in range(nw)]
         pc = ShaderProperty(mgr, T * N, np.float32)
         r = np.random.Generator(np.random.PCG64(1))
         pa.SetValue(r.standard_normal(T * K).astype(np.float16))
-        pw.SetValue((0.02 * r.standard_normal(N * K)).astype(np.float16))
-        line = f"M={T} N={N} K={K}:"
-        for v in (1, 6, 8, 9, 10, 3, 11, 0, 6):
-            for _ in range(3):
-                call("nfai_hip_gemm_f16", mgr.handle, pa.handle, pw.handle, 0, pc.handle, T, N, K, v)
+        w = (0.02 * r.standard_normal(N * K)).astype(np.float16)
+        for pw in pws:
+            pw.SetValue(w)
+        line = f"M={T} N={N} K={K}{' cold' if cold else ''}:"
+        for v in (6, 7, 16, 17, 12, 20, 13, 3, 4, 18, 19, 0):
+            if (v in (12, 14, 20) and N % 80) or (v in (13, 15) and N % 48):
+                continue
+            reps = max(20, nw)
+            for i in range(3):
+                call("nfai_hip_gemm_f16", mgr.handle, pa.handle, pws[i % nw].handle, 0, pc.handle, T, N, K, v)
             mgr.Synchronize()
             mgr.TimerBegin()
-            for _ in range(20):
-                call("nfai_hip_gemm_f16", mgr.handle, pa.handle, pw.handle, 0, pc.handle, T, N, K, v)
-            us = mgr.TimerEnd() * 1e3 / 20
+            for i in range(reps):
+                call("nfai_hip_gemm_f16", mgr.handle, pa.handle, pws[(i + 3) % nw].handle, 0, pc.handle, T, N, K, v)
+            us = mgr.TimerEnd() * 1e3 / reps
             line += f"  {NAMES[v]} {us:6.1f} us ({2.0 * T * N * K / us / 1e6:5.0f} TF)"
         print(line, flush=True)
-        for p in (pa, pw, pc):
+        for p in [pa, pc] + pws:
             mgr.DestoryBuffer(p.buffer)
 
 
