@@ -177,8 +177,13 @@ struct AttnArgs {
     uint32_t *err = nullptr;
 };
 constexpr uint32_t ATTN_NSPLIT_MAX = 32;
-size_t attn_partials_bytes(uint32_t H, uint32_t Hkv, uint32_t D);
+size_t attn_partials_bytes(uint32_t H, uint32_t Hkv, uint32_t D, bool granules = false);  // granules: the {value, tag} form (AttnArgs::epoch set)
 hipError_t launch_attn_decode(const AttnArgs &a, hipStream_t s);
+size_t attn_wo_extra_bytes(uint32_t H, uint32_t D);  // workspace behind attn_partials_bytes(…, true) for the fused launch below
+// attention + (Wo + residual) in ONE launch (kernels_attn.hip, k_attn_wo): `g` is the Wo launch that would follow `a` (x = a.o).
+// attn_wo_ok: the shapes / modes it is built for; everything else takes the two launches.
+bool attn_wo_ok(const AttnArgs &a, const GemvArgs &g);
+hipError_t launch_attn_wo(const AttnArgs &a, const GemvArgs &g, hipStream_t s);
 
 // the weight-streaming engine (kernels_engine.hip): Wo + residual -> gate|up -> Wdown + residual -> next block's q|k|v, one launch
 struct EngineArgs {

@@ -47,6 +47,14 @@ struct AttnParams {
     const uint32_t *epoch;
     uint32_t tag_mul, tag_add;
     uint32_t *err;
+    // fused attention + Wo launch (k_attn_wo): the merged attention output also travels as granules [H*D], read by the Wo waves
+    uint64_t *att_gran;
+    const uint8_t *wo;       // fp16 [E][HD]
+    const float *wo_res;     // residual [E]
+    float *wo_y;             // [E]
+    uint32_t E, HD, nbw;     // Wo rows, row length, workgroups that share the rows
+    uint32_t wo_lds_off;     // byte offset of the Wo waves' LDS region (after the attention waves')
+    uint32_t wo_delay;       // x 64 clocks between launch start and the Wo waves' weight requests (workgroups that run a slice)
     NFAI_STAMP_PARAM
 };
 
@@ -107,8 +115,11 @@ __device__ __forceinline__ void publish(uint64_t *g, uint32_t tag, float v)
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int LPP, int G, bool F16, bool ONLINE, bool POLL>
-__global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
+// The attention waves' program.  PUB: the merged output is also published as {value, tag} granules (p.att_gran) for the Wo waves of
+// the fused launch; every path through the body executes three workgroup barriers, the block of the last slice a fourth
+// (k_attn_wo's Wo waves execute the same number).
+template <int LPP, int G, bool F16, bool ONLINE, bool POLL, bool PUB>
+__device__ __forceinline__ void attn_body(const AttnParams &p, const uint32_t kvh, const uint32_t split)
 {
     constexpr int D = LPP * 4;
     constexpr int NGRP = ATTN_BLOCK / LPP;  // position groups per block
@@ -117,12 +128,11 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
     const uint32_t S = p.pos[0] + 1;
     uint32_t nsplit, chunk;
     attn_split(S, p.min_chunk, p.max_split, nsplit, chunk);
-    const uint32_t kvh = blockIdx.x, split = blockIdx.y;
     if (split >= nsplit) return;
     STAMP_DECL;
     STAMP(0);
 #ifdef NFAI_STAMPS
-    const uint32_t stamp_wave = (blockIdx.y * gridDim.x + blockIdx.x) * (ATTN_BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t stamp_wave = (split * p.Hkv + kvh) * (ATTN_BLOCK / 64) + (threadIdx.x >> 6);
 #endif
     const uint32_t t0 = split * chunk, t1 = min(t0 + chunk, S), n = t1 - t0;
 
@@ -349,6 +359,10 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
                 if (pi * 2 < (uint32_t)G * D) {
                     const float inv = 1.0f / stat[g * 2 + 1];  // AttentionSoftmaxShader.cs:172-176: e * (1/sum)
                     *reinterpret_cast<f32x2 *>(p.o + (uint64_t)(kvh * G + g) * D + d) = f32x2{s0 * inv, s1 * inv};
+                    if constexpr (PUB) {
+                        publish(p.att_gran + (uint64_t)(kvh * G + g) * D + d, tag, s0 * inv);
+                        publish(p.att_gran + (uint64_t)(kvh * G + g) * D + d + 1, tag, s1 * inv);
+                    }
                 }
             } else if (split + 1 < nsplit && pi * 2 < (uint32_t)G * D) {
                 uint64_t *row = gbase + ((uint64_t)split * G + g) * ROW;
@@ -441,6 +455,10 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
                 o1 = fmaf(own[it][1], wo, o1);
                 const float inv = stat[16 + g];
                 *reinterpret_cast<f32x2 *>(p.o + (uint64_t)(kvh * G + g) * D + d) = f32x2{o0 * inv, o1 * inv};
+                if constexpr (PUB) {
+                    publish(p.att_gran + (uint64_t)(kvh * G + g) * D + d, tag, o0 * inv);
+                    publish(p.att_gran + (uint64_t)(kvh * G + g) * D + d + 1, tag, o1 * inv);
+                }
             }
         }
 #ifdef NFAI_STAMPS
@@ -527,13 +545,164 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
     }
 }
 
-size_t attn_partials_bytes(uint32_t H, uint32_t Hkv, uint32_t D)
+template <int LPP, int G, bool F16, bool ONLINE, bool POLL>
+__global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
+{
+    attn_body<LPP, G, F16, ONLINE, POLL, false>(p, blockIdx.x, blockIdx.y);
+}
+
+// ---- attention + Wo in one launch ------------------------------------------------------------------------------------------
+// Workgroup = four attention waves (the program above, kv head = id % Hkv, slice = id / Hkv) + four Wo waves.  The Wo waves
+// request their share of Wo (rows id*E/nbw ..., R rows x U KiB per wave, straight to registers, non-temporal) and the residual at
+// the START of the launch, so the weight stream overlaps the whole attention; then they take part in the attention waves'
+// workgroup barriers (raw s_barrier: no drain of the loads in flight), poll the merged attention output — {value, tag}
+// granules published by the blocks of the last slices — into LDS, meet on an LDS counter and finish with R x U dot products
+// per lane from registers.  Saves one kernel boundary and the Wo launch's own first-byte latency per block (TransformerBlock.cs:
+// 144-161 in one launch).  Every poll is bounded; a poll that gives up sets the error word and the Wo waves store nothing.
+constexpr uint32_t WO_WAVES = 4;
+
+__device__ __forceinline__ uint32_t wo_xs_index(uint32_t k)  // the activation layout of kernels_gemv.hip (fp16 weights)
+{
+    const uint32_t chunk = k >> 9, within = k & 511;
+    return (chunk << 9) + (((within >> 2) & 1) << 8) + ((within >> 3) << 2) + (within & 3);
+}
+
+template <int LPP, int G, bool F16, int R, int U>
+__global__ __launch_bounds__(ATTN_BLOCK + WO_WAVES * 64) void k_attn_wo(const AttnParams p)
+{
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t kvh = blockIdx.x % p.Hkv, split = blockIdx.x / p.Hkv;
+    if (wave < ATTN_BLOCK / 64) {
+        if (split < p.max_split) attn_body<LPP, G, F16, false, true, true>(p, kvh, split);
+        return;
+    }
+    // ---- Wo waves ----------------------------------------------------------------------------------------------------------
+    if (blockIdx.x >= p.nbw) return;
+    typedef __attribute__((address_space(1))) uint8_t g_u8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *xs = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(smem) + p.wo_lds_off);  // HD floats, permuted
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(xs + p.HD);                                     // one arrival word per Wo wave
+    const uint32_t ww = wave - ATTN_BLOCK / 64, lane = threadIdx.x & 63;
+    const uint32_t rb = (uint32_t)(((uint64_t)p.E * blockIdx.x) / p.nbw), re = (uint32_t)(((uint64_t)p.E * (blockIdx.x + 1)) / p.nbw);
+    STAMP_DECL;
+    STAMP(0);
+#ifdef NFAI_STAMPS
+    const uint32_t stamp_wave = p.Hkv * p.max_split * (ATTN_BLOCK / 64) + blockIdx.x * WO_WAVES + ww;  // behind the attention waves' rows
+#endif
+    // (1) the weights and the residual, requested a little after the slice's own K and V rows (below); then the attention waves'
+    //     barriers: three per active slice, a fourth in the block of the last slice (see attn_body).
+    uint32_t nsplit, chunk;
+    attn_split(p.pos[0] + 1, p.min_chunk, p.max_split, nsplit, chunk);
+    const bool has_slice = split < nsplit;
+    // this wave's arrival word is cleared BEFORE a workgroup barrier and read by the others only after it: LDS keeps what an
+    // earlier launch left there, and another model's launch may have left this very tag
+    if (lane == 0) __hip_atomic_store(&cnt[ww], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // A CU's memory requests are served in order.  Requested at once, 18 KB of weights per wave sit in front of the slice's K and V
+    // rows; requested after the slice's first barrier (scores in LDS, 3 us in) the stream is still arriving when the slice
+    // publishes and the polls of the hand-off queue behind it.  Measured optimum (3B, positions 520-647; tokens/s): no delay 626,
+    // 0.8 us 624, 1.3 us 631, 1.6 us 631, 1.9 us 628, 2.3 us 624, 3.2 us 613, after barrier 1: 618 (two launches: 621).
+    if (has_slice)
+        for (uint32_t i = 0; i < p.wo_delay; i++) __builtin_amdgcn_s_sleep(1);  // 64 clocks each
+    asm volatile("" ::: "memory");
+    u32x4 w[R][U];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t row = min(rb + ww * R + r, p.E - 1);
+        const g_u8 *src = (const g_u8 *)p.wo + (uint64_t)row * p.HD * 2 + lane * 16;
+#pragma unroll
+        for (int u = 0; u < U; u++) w[r][u] = load_nt16((const void *)(src + u * 1024));
+    }
+    const float e = ((const __attribute__((address_space(1))) float *)p.wo_res)[min(rb + ww * R + min(lane, (uint32_t)R - 1), p.E - 1)];
+    asm volatile("" ::: "memory");
+    STAMP(1);  // weights requested
+    __builtin_amdgcn_s_barrier();  // slice: barrier 1 of the attention waves; no slice: those waves end without a barrier
+    if (has_slice) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+        if (nsplit > 1 && split + 1 == nsplit) __builtin_amdgcn_s_barrier();
+    }
+    STAMP(2);  // the attention waves of this workgroup are done with barriers
+    // (3) the attention output: this wave's quarter of the HD granules, 16-byte sc1 loads (two granules), until every tag matches
+    const uint32_t tag = p.epoch[0] * p.tag_mul + p.tag_add;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.att_gran, 0, (int)(p.HD * 8), 0x00020000);
+    u32x4 v[U];
+    bool ok = false;
+    for (uint32_t spins = 0; spins < ATTN_SPIN_CAP; spins++) {
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((ww * U + u) * 64 + lane) * 16), 0, 16));
+        ok = true;
+#pragma unroll
+        for (int u = 0; u < U; u++) ok = ok && v[u][1] == tag && v[u][3] == tag;
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    const bool good = __all(ok);
+    STAMP(3);  // this wave's quarter of the attention output seen
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const f32x4 vf = __builtin_bit_cast(f32x4, v[u]);  // whole-vector cast (on an ELEMENT lvalue hipcc 7.2 reads element 0)
+        const uint32_t k = (((ww * U + u) * 64 + lane) * 2);
+        *reinterpret_cast<f32x2 *>(xs + wo_xs_index(k)) = f32x2{vf[0], vf[2]};  // k is even: the pair stays adjacent under the permutation
+    }
+    // (4) the four Wo waves meet on LDS words (the attention waves are done with barriers, some have ended): word ww = this launch's
+    //     tag once wave ww's quarter is in LDS (tag + 1: its poll gave up)
+    if (lane == 0) {
+        if (!good && p.err) __hip_atomic_fetch_or(p.err, 0x2000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&cnt[ww], good ? tag : tag + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    for (uint32_t spins = 0;; spins++) {
+        uint32_t seen = 0, bad = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < WO_WAVES; i++) {
+            const uint32_t a = __hip_atomic_load(&cnt[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            seen += (a == tag || a == tag + 1) ? 1u : 0u;
+            bad += (a == tag + 1) ? 1u : 0u;
+        }
+        if (bad) return;
+        if (seen == WO_WAVES) break;
+        if (spins > (1u << 22)) {
+            if (lane == 0 && p.err) __hip_atomic_fetch_or(p.err, 0x4000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    STAMP(4);  // all four quarters in LDS
+    // (5) R rows x U KiB from registers
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4 *>(xs + (u << 9) + (lane << 2));
+        const f32x4 x1 = *reinterpret_cast<const f32x4 *>(xs + (u << 9) + 256 + (lane << 2));
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = dot8_f16(w[r][u], x0, x1, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = wave_sum(acc[r]);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t row = rb + ww * R + r;
+        if (lane == (uint32_t)r && row < re) p.wo_y[row] = e + acc[r];  // host residual add of TransformerBlock.cs:153-158
+    }
+#ifdef NFAI_STAMPS
+    STAMP(5);  // weights landed, multiplied, reduced, stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(6);
+    STAMP_FLUSH(p.stamps, stamp_wave, 7);
+#endif
+}
+
+size_t attn_partials_bytes(uint32_t H, uint32_t Hkv, uint32_t D, bool granules)
 {
     // one ticket word per kv head (256 B reserved), then partial outputs + (max, sum) per (head, slice): 4-byte words in the ticket
     // form, 8-byte {value, tag} granules in the polling form
     (void)Hkv;
-    return (size_t)H * ATTN_NSPLIT_MAX * (D + 2) * sizeof(uint64_t) + 256;
+    return (size_t)H * ATTN_NSPLIT_MAX * (D + 2) * (granules ? sizeof(uint64_t) : sizeof(float)) + 256;
 }
+
+size_t attn_wo_extra_bytes(uint32_t H, uint32_t D) { return (size_t)H * D * sizeof(uint64_t) + 256; }
 
 template <int LPP, bool F16, bool ONLINE, bool POLL>
 static hipError_t launch_gp(const AttnParams &p, uint32_t G, dim3 grid, size_t lds, hipStream_t s)
@@ -555,13 +724,12 @@ static hipError_t launch_g(const AttnParams &p, uint32_t G, dim3 grid, size_t ld
     return p.epoch ? launch_gp<LPP, F16, ONLINE, true>(p, G, grid, lds, s) : launch_gp<LPP, F16, ONLINE, false>(p, G, grid, lds, s);
 }
 
-hipError_t launch_attn_decode(const AttnArgs &a, hipStream_t s)
+static hipError_t fill_params(const AttnArgs &a, AttnParams &p, dim3 &grid, size_t &lds, bool &online)
 {
     if (a.Hkv == 0 || a.H % a.Hkv != 0 || a.Hkv > 64) return hipErrorInvalidValue;
     const uint32_t G = a.H / a.Hkv;
     if (G > ATTN_GMAX) return hipErrorInvalidValue;
     if (a.D != 64 && a.D != 128) return hipErrorInvalidValue;
-    AttnParams p{};
     p.q = a.q; p.kc = a.kcache; p.vc = a.vcache;
     p.pos_stride = a.kv_pos_stride; p.head_stride = a.kv_head_stride;
     // workspace layout: [64 ticket words (zero between launches)] [partials]; the tickets sit at a
@@ -585,22 +753,109 @@ hipError_t launch_attn_decode(const AttnArgs &a, hipStream_t s)
     max_chunk = (max_chunk + 3) & ~3u;
     if (max_chunk < 2 * ATTN_NSPLIT_MAX) max_chunk = 2 * ATTN_NSPLIT_MAX;
     const uint32_t lpp = a.D / 4, ngrp = ATTN_BLOCK / lpp;
-    const size_t lds = (64 + (size_t)G * max_chunk + (size_t)G * ngrp * a.D + 64 + (size_t)G * ngrp * 2) * sizeof(float);  // + group stats of the one-pass form
+    lds = (64 + (size_t)G * max_chunk + (size_t)G * ngrp * a.D + 64 + (size_t)G * ngrp * 2) * sizeof(float);  // + group stats of the one-pass form
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    const dim3 grid(a.Hkv, p.max_split);
-    const bool f16 = a.kv_type == NFAI_F16;
-    NFAI_STAMP_SET(p, "attn_decode", a.Hkv * p.max_split, ATTN_BLOCK);
+    grid = dim3(a.Hkv, p.max_split);
     // One-pass (online softmax, v_exp_f32) or two-pass form.  The position is device-side, so the choice is made from the KV
     // capacity the model was created with: above 2048 positions the one-pass form (8192 positions: 520 vs 493 tokens/s at
     // 3B), otherwise the two-pass form, which mirrors the reference's three dispatches literally (max, exp(clamp), sum with
     // libm expf) and is as fast at a few hundred positions (611 vs 610).  NFAI_ATTN_ONLINE=0/1 overrides.
     static const int env_online = getenv("NFAI_ATTN_ONLINE") ? atoi(getenv("NFAI_ATTN_ONLINE")) : -1;
-    if (env_online == 1 || (env_online < 0 && a.C > 2048)) {
+    online = env_online == 1 || (env_online < 0 && a.C > 2048);
+    return hipSuccess;
+}
+
+hipError_t launch_attn_decode(const AttnArgs &a, hipStream_t s)
+{
+    AttnParams p{};
+    dim3 grid;
+    size_t lds = 0;
+    bool online = false;
+    hipError_t e = fill_params(a, p, grid, lds, online);
+    if (e != hipSuccess) return e;
+    const uint32_t G = a.H / a.Hkv;
+    const bool f16 = a.kv_type == NFAI_F16;
+    NFAI_STAMP_SET(p, "attn_decode", a.Hkv * p.max_split, ATTN_BLOCK);
+    if (online) {
         if (a.D == 64) return f16 ? launch_g<16, true, true>(p, G, grid, lds, s) : launch_g<16, false, true>(p, G, grid, lds, s);
         return f16 ? launch_g<32, true, true>(p, G, grid, lds, s) : launch_g<32, false, true>(p, G, grid, lds, s);
     }
     if (a.D == 64) return f16 ? launch_g<16, true, false>(p, G, grid, lds, s) : launch_g<16, false, false>(p, G, grid, lds, s);
     return f16 ? launch_g<32, true, false>(p, G, grid, lds, s) : launch_g<32, false, false>(p, G, grid, lds, s);
+}
+
+// ---- attention + Wo: the shapes it is built for (anything else takes the two launches) -------------------------------------
+struct AttnWoShape { uint32_t lpp, G, R, U; };
+static const AttnWoShape kAttnWoShapes[] = {
+    {32, 3, 3, 6},  // Llama-3.2-3B: 24/8 heads of 128, E = HD = 3072 over 256 workgroups
+    {32, 4, 4, 8},  // Llama-3.1-8B: 32/8 heads of 128, E = HD = 4096
+    {16, 4, 2, 4},  // Llama-3.2-1B: 32/8 heads of 64, E = HD = 2048
+    {32, 2, 1, 1},  // test model: 4/2 heads of 128, E = HD = 512 over 128 workgroups
+};
+
+static bool attn_wo_plan(const AttnArgs &a, const GemvArgs &g, uint32_t &nbw, AttnWoShape &shape)
+{
+    static const int env = getenv("NFAI_ATTN_WO") ? atoi(getenv("NFAI_ATTN_WO")) : 1;
+    static const int env_poll = getenv("NFAI_ATTN_POLL") ? atoi(getenv("NFAI_ATTN_POLL")) : 1;
+    static const int env_online = getenv("NFAI_ATTN_ONLINE") ? atoi(getenv("NFAI_ATTN_ONLINE")) : -1;
+    if (!env || !env_poll || env_online == 1 || !a.epoch || a.C > 2048) return false;
+    if (g.w_type != NFAI_F16 || g.mode != GEMV_RESIDUAL || g.gamma || !g.res || g.x != a.o) return false;
+    if (a.Hkv == 0 || a.H % a.Hkv || (a.D != 64 && a.D != 128)) return false;
+    const uint32_t HD = a.H * a.D, E = g.seg_rows[0];
+    if (g.K != HD || HD % 512 || E == 0) return false;
+    nbw = E / 4 < a.n_cu ? E / 4 : a.n_cu;
+    if (nbw == 0) return false;
+    const uint32_t rows = (E + nbw - 1) / nbw;
+    shape = AttnWoShape{a.D / 4, a.H / a.Hkv, (rows + WO_WAVES - 1) / WO_WAVES, HD / 512};
+    for (const AttnWoShape &k : kAttnWoShapes)
+        if (k.lpp == shape.lpp && k.G == shape.G && k.R == shape.R && k.U == shape.U) return true;
+    return false;
+}
+
+bool attn_wo_ok(const AttnArgs &a, const GemvArgs &g)
+{
+    uint32_t nbw;
+    AttnWoShape sh;
+    return attn_wo_plan(a, g, nbw, sh);
+}
+
+template <int LPP, int G, int R, int U>
+static hipError_t launch_aw(const AttnParams &p, bool f16, uint32_t nblocks, size_t lds, hipStream_t s)
+{
+    if (f16) hipLaunchKernelGGL((k_attn_wo<LPP, G, true, R, U>), dim3(nblocks), dim3(ATTN_BLOCK + WO_WAVES * 64), lds, s, p);
+    else hipLaunchKernelGGL((k_attn_wo<LPP, G, false, R, U>), dim3(nblocks), dim3(ATTN_BLOCK + WO_WAVES * 64), lds, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_attn_wo(const AttnArgs &a, const GemvArgs &g, hipStream_t s)
+{
+    uint32_t nbw;
+    AttnWoShape sh;
+    if (!attn_wo_plan(a, g, nbw, sh)) return hipErrorInvalidValue;
+    AttnParams p{};
+    dim3 grid;
+    size_t lds = 0;
+    bool online = false;
+    hipError_t e = fill_params(a, p, grid, lds, online);
+    if (e != hipSuccess) return e;
+    if (online || !p.epoch) return hipErrorInvalidValue;
+    const uint32_t HD = a.H * a.D;
+    // the merged attention output as granules sits behind the slices' granules in the workspace
+    p.att_gran = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(a.partials) + attn_partials_bytes(a.H, a.Hkv, a.D, true));
+    p.wo = static_cast<const uint8_t *>(g.W[0]); p.wo_res = g.res; p.wo_y = g.y;
+    p.E = g.seg_rows[0]; p.HD = HD; p.nbw = nbw;
+    static const int env_delay = getenv("NFAI_ATTN_WO_DELAY") ? atoi(getenv("NFAI_ATTN_WO_DELAY")) : 54;  // x 64 clocks = 1.4 us
+    p.wo_delay = env_delay >= 0 && env_delay < 4096 ? (uint32_t)env_delay : 54;
+    p.wo_lds_off = (uint32_t)((lds + 15) & ~(size_t)15);
+    lds = p.wo_lds_off + ((size_t)HD + 16) * sizeof(float);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    const uint32_t nblocks = a.Hkv * p.max_split > nbw ? a.Hkv * p.max_split : nbw;
+    NFAI_STAMP_SET(p, "attn_wo", nblocks, ATTN_BLOCK + WO_WAVES * 64);
+    const bool f16 = a.kv_type == NFAI_F16;
+    if (sh.lpp == 32 && sh.G == 3) return launch_aw<32, 3, 3, 6>(p, f16, nblocks, lds, s);
+    if (sh.lpp == 32 && sh.G == 4) return launch_aw<32, 4, 4, 8>(p, f16, nblocks, lds, s);
+    if (sh.lpp == 16 && sh.G == 4) return launch_aw<16, 4, 2, 4>(p, f16, nblocks, lds, s);
+    return launch_aw<32, 2, 1, 1>(p, f16, nblocks, lds, s);
 }
 
 }  // namespace nfai

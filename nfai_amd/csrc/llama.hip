@@ -342,7 +342,7 @@ int submit_qkv(Model *m, Layer &L, const float *x, Sched &sch)
 }
 
 // scores + softmax + weighted V of block L in one launch (TransformerBlock.cs:144-148)
-int submit_attn(Model *m, Layer &L, Sched &sch)
+AttnArgs attn_args(Model *m, Layer &L)
 {
     const nfai_llama_desc &d = m->d;
     AttnArgs a;
@@ -354,19 +354,26 @@ int submit_attn(Model *m, Layer &L, Sched &sch)
     a.n_cu = (uint32_t)m->ctx->prop.multiProcessorCount;
     // slice hand-off by {value, tag} granules: tag = token epoch x blocks + block (never the tag of an earlier launch on this workspace)
     a.epoch = m->d_epoch; a.tag_mul = (uint32_t)m->layers.size() + 1; a.tag_add = (uint32_t)(&L - m->layers.data()) + 1; a.err = m->d_engerr;
-    return sch.submit(op_attn(KC_ATTN, a));
+    return a;
 }
+
+int submit_attn(Model *m, Layer &L, Sched &sch) { return sch.submit(op_attn(KC_ATTN, attn_args(m, L))); }
 
 // One block, fused path (TransformerBlock.cs:127-184 in five launches + the attention merge).
 int block_fused(Model *m, Layer &L, Sched &sch)
 {
     const nfai_llama_desc &d = m->d;
     S_TRY(submit_qkv(m, L, m->x, sch));
-    S_TRY(submit_attn(m, L, sch));
     {
         GemvArgs a = gemv_base(m, L.wo, m->att, d.H * d.D);
         a.mode = GEMV_RESIDUAL; a.res = m->x; a.y = m->h;
-        S_TRY(sch.submit(op_gemv(KC_WO, a)));
+        const AttnArgs at = attn_args(m, L);
+        if (attn_wo_ok(at, a)) {  // attention + Wo + residual in one launch (fp16 Wo, the shapes of kernels_attn.hip's table)
+            S_TRY(sch.submit(op_fn(KC_ATTN, [at, a](hipStream_t st) { return launch_attn_wo(at, a, st); })));
+        } else {
+            S_TRY(sch.submit(op_attn(KC_ATTN, at)));
+            S_TRY(sch.submit(op_gemv(KC_WO, a)));
+        }
     }
     {
         GemvArgs a = gemv_base(m, L.wgate, m->h, d.E);
@@ -656,7 +663,7 @@ NFAI_API int32_t nfai_hip_llama_create(nfai_ctx_t ch, const nfai_llama_desc *des
     DALLOC(m->d_epoch, 256);
     DALLOC(m->d_engerr, 256);
     if (m->engine) DALLOC(m->d_gran, (size_t)m->layers.size() * (2 * (size_t)d.E + d.F) * 8);
-    DALLOC(m->d_attn_part, attn_partials_bytes(d.H, d.Hkv, d.D));
+    DALLOC(m->d_attn_part, attn_partials_bytes(d.H, d.Hkv, d.D, true) + attn_wo_extra_bytes(d.H, d.D));
     DALLOC(m->x, d.E * 4);
     DALLOC(m->h, d.E * 4);
     DALLOC(m->q, d.H * d.D * 4);

@@ -177,6 +177,21 @@ def test_prefill_mfma_kquant(mgr, n, chunk):
     m.Dispose()
 
 
+def test_prefill_fused_dequant_in_child_process():
+    """The dequant-in-LDS prefill (k_gemm_kq, NFAI_PREFILL_FUSED=1) at model level.  The switch is read once per process, so the
+    same Q4_K_M-style prefill test runs again in a child process with the variable set; the child's interpreter loads the
+    library itself (nothing is inherited but the environment)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, NFAI_PREFILL_FUSED="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kquant.py"), "-m", "gpu", "-x", "-q",
+                        "-k", "test_prefill_mfma_kquant", "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "2 passed" in r.stdout, r.stdout[-2000:]
+
+
 @pytest.mark.parametrize("qt", [Q4_K, Q6_K])
 @pytest.mark.parametrize("M,N,K,res", [(256, 512, 1024, True), (100, 64, 256, False), (512, 3072, 768, False)])
 def test_gemm_kq_dequant_in_lds(mgr, qt, M, N, K, res):

@@ -105,6 +105,16 @@ def main():
                           "launches": len(eng_span), "span_us": pct(eng_span),
                           "roles": {r: {names[r][k]: med(v, k) for k in range(len(names[r]))} for r, v in eng.items()}}, indent=1))
         return
+    aw = {"attention waves": [], "wo waves": [], "span": []}
+    for s, (name, grid, block) in enumerate(infos):
+        if name != "attn_wo":
+            continue
+        t = st[s]
+        t0 = t[t[:, 0] > 0][:, 0].min()
+        rel = np.where(t > 0, t - t0, np.nan)
+        aw["attention waves"].append(rel[:1024])
+        aw["wo waves"].append(rel[1024:1024 + grid * 4])
+        aw["span"].append(float(np.nanmax(rel)))
     for s, (name, grid, block) in enumerate(infos):
         t = st[s]
         live = t[:, 0] > 0
@@ -153,6 +163,18 @@ def main():
     for k, d in per_cls.items():
         out["classes"][k] = {kk: pct(v) for kk, v in d.items() if len(v)}
         out["classes"][k]["launches"] = len(d["span"])
+    if aw["span"]:
+        def col(rows, k):
+            a_ = np.concatenate(rows)[:, k]
+            a_ = a_[~np.isnan(a_)]
+            return (pct(a_) + [round(float(a_.max()), 3)]) if a_.size else None
+        an = ["start", "K, V, q requested", "scores in LDS", "softmax done", "granules / output issued", "last slice: all granules seen", "-", "last slice: merged output published"]
+        wn = ["start", "weights requested", "attention waves of the workgroup done with barriers", "quarter of the attention output seen",
+              "all four quarters in LDS", "multiplied, reduced, stores issued", "stores acknowledged"]
+        out["attn_wo"] = {"what": "fused attention + Wo launch: time of each event since the launch's first stamp, us, [median, p10, p90, max] over the waves of the role, all blocks' launches of one token",
+                          "span_us": pct(aw["span"]),
+                          "attention waves": {an[k]: col(aw["attention waves"], k) for k in range(8) if an[k] != "-"},
+                          "wo waves": {wn[k]: col(aw["wo waves"], k) for k in range(7)}}
     if launches:
         out["token_span_us"] = round(launches[-1]["t1"] - launches[0]["t0"], 2)
     print(json.dumps(out, indent=1))
