@@ -116,8 +116,8 @@ __device__ __forceinline__ void publish(uint64_t *g, uint32_t tag, float v)
 }
 
 // The attention waves' program.  PUB: the merged output is also published as {value, tag} granules (p.att_gran) for the Wo waves of
-// the fused launch; every path through the body executes three workgroup barriers, the block of the last slice a fourth
-// (k_attn_wo's Wo waves execute the same number).
+// the fused launch; every path through the body executes three workgroup barriers and, when the context has more than one slice,
+// a fourth (k_attn_wo's Wo waves execute the same number).
 template <int LPP, int G, bool F16, bool ONLINE, bool POLL, bool PUB>
 __device__ __forceinline__ void attn_body(const AttnParams &p, const uint32_t kvh, const uint32_t split)
 {
@@ -336,16 +336,18 @@ __device__ __forceinline__ void attn_body(const AttnParams &p, const uint32_t kv
     if (POLL && tid == 0) stat[32] = 0.f;
     __syncthreads();
     if constexpr (POLL) {
-        // ---- granule hand-off: slices 0..nsplit-2 publish {value, tag} and leave; the block of the LAST slice (the shortest one)
-        //      keeps its own sums, polls the other slices' granules and merges in the fixed order 0..nsplit-1 -----------------------
+        // ---- granule hand-off, merge spread over the slices' own blocks: every block publishes its sums and (max, sum of exp) as
+        //      {value, tag} granules, then merges ITS share of the kv head's G*D outputs (elements [GD*split/nsplit, GD*(split+1)/
+        //      nsplit)) over all slices in the fixed order 0..nsplit-1.  A block polls a few hundred granules instead of one block
+        //      per kv head polling all of them: a pass is one short memory round trip, and a retry costs little ---------------------
         constexpr uint32_t ROW = D + 2;  // granules per (slice, query head): D sums, slice max, slice sum of exp
+        constexpr uint32_t GD = (uint32_t)G * D;
         const uint32_t tag = p.epoch[0] * p.tag_mul + p.tag_add;
         uint64_t *gbase = reinterpret_cast<uint64_t *>(p.partials) + (uint64_t)kvh * ATTN_NSPLIT_MAX * G * ROW;
-        constexpr int PIT = (G * D / 2 + ATTN_BLOCK - 1) / ATTN_BLOCK;  // element PAIRS per thread
-        f32x2 own[PIT];
+        constexpr int PIT = (GD / 2 + ATTN_BLOCK - 1) / ATTN_BLOCK;  // element PAIRS per thread
 #pragma unroll
         for (int it = 0; it < PIT; it++) {
-            const uint32_t pi = tid + it * ATTN_BLOCK, e = min(pi * 2, (uint32_t)G * D - 2);
+            const uint32_t pi = tid + it * ATTN_BLOCK, e = min(pi * 2, GD - 2);
             const uint32_t g = e / D, d = e % D;
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll 4
@@ -354,67 +356,60 @@ __device__ __forceinline__ void attn_body(const AttnParams &p, const uint32_t kv
                 s0 += v[0];
                 s1 += v[1];
             }
-            own[it] = f32x2{s0, s1};
-            if (nsplit == 1) {
-                if (pi * 2 < (uint32_t)G * D) {
+            if (pi * 2 < GD) {
+                if (nsplit == 1) {
                     const float inv = 1.0f / stat[g * 2 + 1];  // AttentionSoftmaxShader.cs:172-176: e * (1/sum)
                     *reinterpret_cast<f32x2 *>(p.o + (uint64_t)(kvh * G + g) * D + d) = f32x2{s0 * inv, s1 * inv};
                     if constexpr (PUB) {
                         publish(p.att_gran + (uint64_t)(kvh * G + g) * D + d, tag, s0 * inv);
                         publish(p.att_gran + (uint64_t)(kvh * G + g) * D + d + 1, tag, s1 * inv);
                     }
+                } else {
+                    uint64_t *row = gbase + ((uint64_t)split * G + g) * ROW;
+                    publish(row + d, tag, s0);
+                    publish(row + d + 1, tag, s1);
                 }
-            } else if (split + 1 < nsplit && pi * 2 < (uint32_t)G * D) {
-                uint64_t *row = gbase + ((uint64_t)split * G + g) * ROW;
-                publish(row + d, tag, s0);
-                publish(row + d + 1, tag, s1);
             }
         }
         if (nsplit == 1) { STAMP_FLUSH(p.stamps, stamp_wave, 4); return; }
-        if (split + 1 < nsplit) {
-            if (tid < (uint32_t)G) {
-                uint64_t *row = gbase + ((uint64_t)split * G + tid) * ROW;
-                publish(row + D, tag, stat[tid * 2]);
-                publish(row + D + 1, tag, stat[tid * 2 + 1]);
-            }
-            STAMP(4);  // V phase, LDS reduction, granules issued
-            STAMP_FLUSH(p.stamps, stamp_wave, 5);
-            return;
+        if (tid < (uint32_t)G) {
+            uint64_t *row = gbase + ((uint64_t)split * G + tid) * ROW;
+            publish(row + D, tag, stat[tid * 2]);
+            publish(row + D + 1, tag, stat[tid * 2 + 1]);
         }
-        STAMP(4);
-        const uint32_t ns1 = nsplit - 1;  // published slices
+        STAMP(4);  // V phase, LDS reduction, granules issued
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)gbase, 0, (int)(ATTN_NSPLIT_MAX * G * ROW * 8), 0x00020000);
         float *mw = sc;           // [G][NSPLIT_MAX] merge weights exp(m_s - M), zero for inactive slices — sc is free now
         float *flag = stat + 32;  // non-zero: a poll gave up (cleared before the barrier above)
         constexpr int NGW = (G + ATTN_BLOCK / 64 - 1) / (ATTN_BLOCK / 64);  // query heads whose merge weights this wave computes
         const uint32_t wv = tid >> 6;
-#pragma unroll
-        for (int it = 0; it < PIT; it++) {
-            const uint32_t pi = tid + it * ATTN_BLOCK, e = min(pi * 2, (uint32_t)G * D - 2);
+        // ONE sweep per pass: the (max, sum of exp) pairs of every query head (one wave per head, lane = slice; this block's own
+        // pair comes from LDS) and all slices of this thread's output element (8-byte sc1 loads), checked together
+        const uint32_t e0 = GD * split / nsplit, e1 = GD * (split + 1) / nsplit;
+        for (uint32_t eb = e0; eb < e1; eb += ATTN_BLOCK) {  // block-uniform trip count (one trip unless GD / nsplit > 256)
+            const bool first = eb == e0;
+            const uint32_t e = min(eb + tid, e1 - 1);
             const uint32_t g = e / D, d = e % D;
-            // ONE sweep per pass: all published slices of this thread's element pair (clamped slice index beyond ns1) and, in the
-            // first sweep, the (max, sum) pairs of the heads this wave weighs (lane = slice) — sc1 loads, L1 bypassed
-            u32x4 a[ATTN_NSPLIT_MAX - 1], sv[NGW];
+            u32x2 a[ATTN_NSPLIT_MAX];
+            u32x4 sv[NGW];
             bool ok = false;
             for (uint32_t spins = 0; spins < ATTN_SPIN_CAP; spins++) {
 #pragma unroll
-                for (int s2 = 0; s2 < (int)ATTN_NSPLIT_MAX - 1; s2++)
-                    a[s2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                        rsrc, (int)((((min((uint32_t)s2, ns1 - 1) * G + g) * ROW) + d) * 8), 0, 16));
-                if (it == 0) {
+                for (int s2 = 0; s2 < (int)ATTN_NSPLIT_MAX; s2++)
+                    a[s2] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)((((min((uint32_t)s2, nsplit - 1) * G + g) * ROW) + d) * 8), 0, 16));
+                if (first) {
 #pragma unroll
                     for (int j = 0; j < NGW; j++) {
                         const uint32_t gh = min(wv + j * (ATTN_BLOCK / 64), (uint32_t)G - 1);
-                        sv[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                            rsrc, (int)((((min(lane, ns1 - 1) * G + gh) * ROW) + D) * 8), 0, 16));
+                        sv[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((((min(lane, nsplit - 1) * G + gh) * ROW) + D) * 8), 0, 16));
                     }
                 }
                 ok = true;
 #pragma unroll
-                for (int s2 = 0; s2 < (int)ATTN_NSPLIT_MAX - 1; s2++) ok = ok && a[s2][1] == tag && a[s2][3] == tag;
-                if (it == 0) {
+                for (int s2 = 0; s2 < (int)ATTN_NSPLIT_MAX; s2++) ok = ok && a[s2][1] == tag;
+                if (first) {
 #pragma unroll
-                    for (int j = 0; j < NGW; j++) ok = ok && sv[j][1] == tag && sv[j][3] == tag;
+                    for (int j = 0; j < NGW; j++) ok = ok && (lane >= nsplit || lane == split || (sv[j][1] == tag && sv[j][3] == tag));
                 }
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(1);
@@ -423,13 +418,13 @@ __device__ __forceinline__ void attn_body(const AttnParams &p, const uint32_t kv
                 flag[0] = 1.f;
                 if (lane == 0 && p.err) __hip_atomic_fetch_or(p.err, 0x1000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (it == 0) {
+            if (first) {
 #pragma unroll
                 for (int j = 0; j < NGW; j++) {
                     const uint32_t gh = wv + j * (ATTN_BLOCK / 64);
                     if (gh < (uint32_t)G) {  // wave-uniform
                         const f32x4 vf = __builtin_bit_cast(f32x4, sv[j]);
-                        const float m_s = lane == ns1 ? stat[gh * 2] : vf[0], l_s = lane == ns1 ? stat[gh * 2 + 1] : vf[2];
+                        const float m_s = lane == split ? stat[gh * 2] : vf[0], l_s = lane == split ? stat[gh * 2 + 1] : vf[2];
                         const float M = wave_max(lane < nsplit ? m_s : -1.0e38f);
                         const float f = lane < nsplit ? expf(m_s - M) : 0.0f;
                         const float L = wave_sum(lane < nsplit ? l_s * f : 0.0f);
@@ -438,32 +433,24 @@ __device__ __forceinline__ void attn_body(const AttnParams &p, const uint32_t kv
                     }
                 }
                 __syncthreads();
-                STAMP(5);  // every published granule of the first sweep seen, merge weights in LDS
+                STAMP(5);  // every granule of the first sweep seen, merge weights in LDS
             }
             if (flag[0] != 0.f) return;  // a poll gave up (the error word is set): no output is better than a wrong one
-            if (pi * 2 < (uint32_t)G * D) {
-                float o0 = 0.f, o1 = 0.f;
+            if (eb + tid < e1) {
+                float o = 0.f;
 #pragma unroll
-                for (int s2 = 0; s2 < (int)ATTN_NSPLIT_MAX - 1; s2++) {
-                    const f32x4 vf = __builtin_bit_cast(f32x4, a[s2]);
-                    const float w = (uint32_t)s2 < ns1 ? mw[g * ATTN_NSPLIT_MAX + s2] : 0.f;
-                    o0 = fmaf(vf[0], w, o0);
-                    o1 = fmaf(vf[2], w, o1);
+                for (int s2 = 0; s2 < (int)ATTN_NSPLIT_MAX; s2++) {
+                    const f32x2 vf = __builtin_bit_cast(f32x2, a[s2]);
+                    o = fmaf(vf[0], (uint32_t)s2 < nsplit ? mw[g * ATTN_NSPLIT_MAX + s2] : 0.f, o);
                 }
-                const float wo = mw[g * ATTN_NSPLIT_MAX + ns1];
-                o0 = fmaf(own[it][0], wo, o0);
-                o1 = fmaf(own[it][1], wo, o1);
-                const float inv = stat[16 + g];
-                *reinterpret_cast<f32x2 *>(p.o + (uint64_t)(kvh * G + g) * D + d) = f32x2{o0 * inv, o1 * inv};
-                if constexpr (PUB) {
-                    publish(p.att_gran + (uint64_t)(kvh * G + g) * D + d, tag, o0 * inv);
-                    publish(p.att_gran + (uint64_t)(kvh * G + g) * D + d + 1, tag, o1 * inv);
-                }
+                o *= stat[16 + g];
+                p.o[(uint64_t)(kvh * G + g) * D + d] = o;
+                if constexpr (PUB) publish(p.att_gran + (uint64_t)(kvh * G + g) * D + d, tag, o);
             }
         }
 #ifdef NFAI_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        STAMP(7);  // merge done and stored (block of the last slice only)
+        STAMP(7);  // this block's share merged and stored
         STAMP_FLUSH(p.stamps, stamp_wave, 8);
 #endif
         return;
@@ -590,7 +577,7 @@ __global__ __launch_bounds__(ATTN_BLOCK + WO_WAVES * 64) void k_attn_wo(const At
     const uint32_t stamp_wave = p.Hkv * p.max_split * (ATTN_BLOCK / 64) + blockIdx.x * WO_WAVES + ww;  // behind the attention waves' rows
 #endif
     // (1) the weights and the residual, requested a little after the slice's own K and V rows (below); then the attention waves'
-    //     barriers: three per active slice, a fourth in the block of the last slice (see attn_body).
+    //     barriers: three per active slice, a fourth when there is more than one slice (see attn_body).
     uint32_t nsplit, chunk;
     attn_split(p.pos[0] + 1, p.min_chunk, p.max_split, nsplit, chunk);
     const bool has_slice = split < nsplit;
@@ -620,7 +607,7 @@ __global__ __launch_bounds__(ATTN_BLOCK + WO_WAVES * 64) void k_attn_wo(const At
     if (has_slice) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_barrier();
-        if (nsplit > 1 && split + 1 == nsplit) __builtin_amdgcn_s_barrier();
+        if (nsplit > 1) __builtin_amdgcn_s_barrier();
     }
     STAMP(2);  // the attention waves of this workgroup are done with barriers
     // (3) the attention output: this wave's quarter of the HD granules, 16-byte sc1 loads (two granules), until every tag matches

@@ -146,10 +146,9 @@ def main():
                 d["partials_acked"].extend(t[:, 5] - t[:, 4])
                 d["ticket"].extend(t[:, 6] - t[:, 5])
                 d["merge"].extend(mg[:, 7] - mg[:, 6])
-            else:                     # granule hand-off: only the block of the last slice goes on after stamp 4
-                d.setdefault("merger_own_slice_done", []).extend(mg[:, 4] - L["t0"])
-                d.setdefault("slowest_producer_published", []).append(float(t[t[:, 7] == 0][:, 4].max() - L["t0"]) if (t[:, 7] == 0).any() else 0.0)
-                d.setdefault("granules_seen_after_own_slice", []).extend(mg[:, 5] - mg[:, 4])
+            else:                     # granule hand-off: every block merges its share of the outputs after stamp 4
+                d.setdefault("own_slice_published", []).extend(t[:, 4] - L["t0"])
+                d.setdefault("all_granules_seen_after_own_publish", []).extend(mg[:, 5] - mg[:, 4])
                 d.setdefault("merge_and_store", []).extend(mg[:, 7] - mg[:, 5])
         else:
             d["issued"].extend(t[:, 1] - t[:, 0])
@@ -168,7 +167,7 @@ def main():
             a_ = np.concatenate(rows)[:, k]
             a_ = a_[~np.isnan(a_)]
             return (pct(a_) + [round(float(a_.max()), 3)]) if a_.size else None
-        an = ["start", "K, V, q requested", "scores in LDS", "softmax done", "granules / output issued", "last slice: all granules seen", "-", "last slice: merged output published"]
+        an = ["start", "K, V, q requested", "scores in LDS", "softmax done", "own granules issued", "all granules of the share seen, merge weights in LDS", "-", "share of the merged output published"]
         wn = ["start", "weights requested", "attention waves of the workgroup done with barriers", "quarter of the attention output seen",
               "all four quarters in LDS", "multiplied, reduced, stores issued", "stores acknowledged"]
         out["attn_wo"] = {"what": "fused attention + Wo launch: time of each event since the launch's first stamp, us, [median, p10, p90, max] over the waves of the role, all blocks' launches of one token",
