@@ -22,7 +22,7 @@ OBJ_DIR = os.path.join(CSRC, "build")
 ARCH = "gfx950"
 
 SOURCES = ["api.hip", "kernels_basic.hip", "kernels_gemv.hip", "kernels_gemv_kq.hip", "kernels_gemv_kqm.hip", "kernels_attn.hip", "kernels_engine.hip", "kernels_prefill.hip", "llama.hip", "pp.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "nfai_hip.h")]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kqm.h"), os.path.join(ROOT, "include", "nfai_hip.h")]
 
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=hidden", "-Wall",
             "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-variable", "-Wno-unused-but-set-variable",

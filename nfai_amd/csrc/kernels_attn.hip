@@ -786,10 +786,15 @@ static bool attn_wo_plan(const AttnArgs &a, const GemvArgs &g, uint32_t &nbw, At
     static const int env_poll = getenv("NFAI_ATTN_POLL") ? atoi(getenv("NFAI_ATTN_POLL")) : 1;
     static const int env_online = getenv("NFAI_ATTN_ONLINE") ? atoi(getenv("NFAI_ATTN_ONLINE")) : -1;
     if (!env || !env_poll || env_online == 1 || !a.epoch || a.C > 2048) return false;
-    if (g.w_type != NFAI_F16 || g.mode != GEMV_RESIDUAL || g.gamma || !g.res || g.x != a.o) return false;
+    if (g.mode != GEMV_RESIDUAL || g.gamma || !g.res || g.x != a.o) return false;
     if (a.Hkv == 0 || a.H % a.Hkv || (a.D != 64 && a.D != 128)) return false;
     const uint32_t HD = a.H * a.D, E = g.seg_rows[0];
-    if (g.K != HD || HD % 512 || E == 0) return false;
+    if (g.K != HD || E == 0) return false;
+    // (A Q4_K Wo was built into this launch too — one 16-row tile per workgroup, the Wo waves staging their pieces of the attention
+    //  output as fixed-point MFMA fragments after the hand-off — and measured at 3B Q4_K_M: 973 tokens/s against 1019 with the two
+    //  launches.  The staging, integer dot products and cross-wave sum that follow the hand-off take as long as the whole separate
+    //  launch, whose stream is only 7 KB per CU; removed.)
+    if (g.w_type != NFAI_F16 || HD % 512) return false;
     nbw = E / 4 < a.n_cu ? E / 4 : a.n_cu;
     if (nbw == 0) return false;
     const uint32_t rows = (E + nbw - 1) / nbw;
@@ -834,11 +839,11 @@ hipError_t launch_attn_wo(const AttnArgs &a, const GemvArgs &g, hipStream_t s)
     static const int env_delay = getenv("NFAI_ATTN_WO_DELAY") ? atoi(getenv("NFAI_ATTN_WO_DELAY")) : 54;  // x 64 clocks = 1.4 us
     p.wo_delay = env_delay >= 0 && env_delay < 4096 ? (uint32_t)env_delay : 54;
     p.wo_lds_off = (uint32_t)((lds + 15) & ~(size_t)15);
+    const bool f16 = a.kv_type == NFAI_F16;
+    uint32_t nblocks = a.Hkv * p.max_split > nbw ? a.Hkv * p.max_split : nbw;
     lds = p.wo_lds_off + ((size_t)HD + 16) * sizeof(float);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    const uint32_t nblocks = a.Hkv * p.max_split > nbw ? a.Hkv * p.max_split : nbw;
     NFAI_STAMP_SET(p, "attn_wo", nblocks, ATTN_BLOCK + WO_WAVES * 64);
-    const bool f16 = a.kv_type == NFAI_F16;
     if (sh.lpp == 32 && sh.G == 3) return launch_aw<32, 3, 3, 6>(p, f16, nblocks, lds, s);
     if (sh.lpp == 32 && sh.G == 4) return launch_aw<32, 4, 4, 8>(p, f16, nblocks, lds, s);
     if (sh.lpp == 16 && sh.G == 4) return launch_aw<16, 4, 2, 4>(p, f16, nblocks, lds, s);

@@ -3,10 +3,11 @@
 (--pmc FETCH_SIZE, --pmc WRITE_SIZE; with --kernel-trace only), hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (on gfx950
 FETCH_SIZE reports half of a 16 B/lane coalesced stream; WRITE_SIZE is exact).
 
-    tools/pmc_traffic.py f16     -> profiles/round1_pmc_traffic.json          (bench.py reads `traffic` from it)
-    tools/pmc_traffic.py q4_k_m  -> profiles/round1_pmc_traffic_q4km.json
+    tools/pmc_traffic.py f16     -> gpurun_out/round2_pmc_traffic.json       (copied to profiles/; bench.py reads `traffic` from it)
+    tools/pmc_traffic.py q4_k_m  -> gpurun_out/round2_pmc_traffic_q4km.json
 
-Runs on the GPU box (writes under gpurun_out/, then the summary under profiles/)."""
+The profiled command is bench.py at ITS OWN context (512 prompt tokens through the MFMA prefill, then decode steps at
+positions 512...), so the counters belong to the launches the benchmark times.  Runs on the GPU box."""
 import collections
 import csv
 import glob
@@ -17,9 +18,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 quant = sys.argv[1] if len(sys.argv) > 1 else "f16"
-out_json = os.path.join(ROOT, "profiles", "round1_pmc_traffic.json" if quant == "f16" else "round1_pmc_traffic_q4km.json")
-bench = ["python3", os.path.join(ROOT, "bench.py"), "--quant", quant, "--steps", "4", "--warmup", "1", "--context", "16",
-         "--no-cpu-baseline", "--profile-steps", "0", "--no-mfma-prefill"]
+out_json = os.path.join(ROOT, "gpurun_out", "round2_pmc_traffic.json" if quant == "f16" else "round2_pmc_traffic_q4km.json")
+bench = ["python3", os.path.join(ROOT, "bench.py"), "--quant", quant, "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--profile-steps", "0"]
 vals = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     d = os.path.join(ROOT, "gpurun_out", f"pmc_{ctr}_{quant}")
@@ -33,6 +33,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         if r["Counter_Name"] == ctr:
             agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
     vals[ctr] = {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+    subprocess.run(["rm", "-rf", d])  # the raw traces are tens of MB; gpurun copies back at most 64 MiB
 
 # algorithmic bytes per launch of the GEMV kernels at 3B: rows x K x bytes per weight
 E, F, HD, KD = 3072, 8192, 3072, 1024
@@ -40,13 +41,14 @@ ALG = {"nfai::k_gemv<1, 3, 2, 3, false, true>": 2 * F * E * 2, "nfai::k_gemv<1, 
        "nfai::k_gemv<1, 2, 2, 3, false, true>": (HD + 2 * KD) * E * 2, "nfai::k_gemv<1, 1, 3, 3, false, false>": E * HD * 2,
        "nfai::k_gemv_kqt<112, 3, 1, true, 0>": 2 * F * E * 144 // 256, "nfai::k_gemv_kqt<112, 1, 1, false, 1>": E * HD * 144 // 256,
        "nfai::k_gemv_kqt<112, 1, 2, false, 2>": E * F * 144 // 256, "nfai::k_gemv_kqt<114, 1, 2, false, 2>": E * F * 210 // 256}
-out = {"command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --quant %s --steps 4 --warmup 1 "
-                  "--context 16 --no-cpu-baseline --profile-steps 0 --no-mfma-prefill   (second pass with --pmc WRITE_SIZE); tools/pmc_traffic.py" % quant,
+out = {"command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --quant %s --steps 8 --warmup 2 "
+                  "--no-cpu-baseline --profile-steps 0   (second pass with --pmc WRITE_SIZE; the benchmark's own context of 512 tokens); tools/pmc_traffic.py" % quant,
+       "engine": False, "dominant_kernel": "nfai::k_gemv<1, 3, 2, 3, false, true>" if quant == "f16" else "nfai::k_gemv_kqt<112, 3, 1, true, 0>",
        "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE reads exactly 1/2 of a 16 B/lane coalesced stream on gfx950 "
                      "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact",
        "model": "llama-3.2-3b " + ("fp16" if quant == "f16" else "Q4_K_M"), "kernels": {}}
 for k, (fv, n) in vals["FETCH_SIZE"].items():
-    if not k.startswith("nfai::"):
+    if not k.startswith("nfai::") or "k_gemm" in k or "_rows" in k:
         continue
     wv = vals["WRITE_SIZE"].get(k, (0.0, 0))[0]
     e = {"FETCH_SIZE_KB_avg": fv, "launches": n, "WRITE_SIZE_KB_avg": wv, "hbm_bytes_per_launch": (2 * fv + wv) * 1024}

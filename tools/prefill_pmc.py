@@ -68,6 +68,7 @@ def main():
                 if k:
                     agg[(k, row["Grid_Size_X"] if "Grid_Size_X" in row else row.get("Grid_Size"))]["_dur_us_%d" % gi].append(
                         (int(row["Dispatch_Id"]), (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3))
+        subprocess.run(["rm", "-rf", d])  # raw traces: tens of MB (gpurun copies back at most 64 MiB)
     out = {"command": "rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python3 tools/prefill_prof.py   (one pass per group: "
                       + " | ".join(" ".join(g) for g in GROUPS) + "); tools/prefill_pmc.py",
            "note": __doc__.split("\n\n")[2], "kernels": {}}
