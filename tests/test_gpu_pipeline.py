@@ -147,3 +147,24 @@ def test_pp_bad_arguments(env):
         _lib.call("nfai_hip_pp_init", mgr.handle, 3, 2, uid, C.byref(h))
     with pytest.raises(_lib.NfaiHipError, match="invalid pipeline handle"):
         _lib.call("nfai_hip_pp_begin", 12345)
+
+
+def test_bench_two_rank_rehearsal_on_one_card():
+    """`bench.py --gpus 2` started WITHOUT a launcher (the form the driver uses for N = 1) must start its own
+    torch.distributed.run child; with NFAI_PP_REHEARSAL=1 both ranks share device 0 and exchange over gloo: HipStage + TorchComm
+    + the wavefront schedule in two real processes.  Checks the contract fields of the one JSON line rank 0 prints."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NFAI_PP_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--model", "llama-3.2-1b"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["parallelism"] == "pp2" and len(d["config"]["layer_ranges"]) == 2
