@@ -161,6 +161,12 @@ int32_t nfai_hip_gemm_f16(nfai_ctx_t ctx, nfai_buf_t A_f16, nfai_buf_t W_f16, nf
 int32_t nfai_hip_gemm_f16_ex(nfai_ctx_t ctx, nfai_buf_t A_f16, nfai_buf_t W_f16, nfai_buf_t W1_f16, nfai_buf_t R, nfai_buf_t C,
                              uint32_t M, uint32_t N, uint32_t K, int32_t variant, int32_t epi, uint32_t batch, uint32_t b_div,
                              uint32_t causal, uint32_t causal_pos0);
+/* Causal attention of a prompt chunk in ONE launch (the MFMA prefill's attention; the reference runs AttentionScoreCalculationShader.cs:
+ * 164-206, AttentionSoftmaxShader.cs:139-178 and AttentionWeightedValueSumShader.cs:175-216 once per token): Q [T][H*D] fp16 (after
+ * RoPE), K [Hkv][Spad][D] fp16, V^T [Hkv][D][Spad] fp16 (rows / columns past pos0 + T zero), O [T][H*D] fp16; query t sees keys
+ * 0 .. pos0 + t.  D in {64, 128}, Spad %% 32 == 0, pos0 + T <= Spad. */
+int32_t nfai_hip_attn_prefill(nfai_ctx_t ctx, nfai_buf_t Q_f16, nfai_buf_t K_f16, nfai_buf_t Vt_f16, nfai_buf_t O_f16, uint32_t T, uint32_t H,
+                              uint32_t Hkv, uint32_t D, uint32_t Spad, uint32_t pos0);
 /* The same batched product with W in Q4_K / Q6_K blocks (a buffer from nfai_hip_weight_upload with N %% 16 == 0 rows): the
  * dequant-in-LDS GEMM — quantised bytes -> registers -> fp16 tile in LDS -> MFMA; the weights are never widened in HBM. */
 int32_t nfai_hip_gemm_kq(nfai_ctx_t ctx, nfai_buf_t A_f16, nfai_buf_t W, int32_t w_type, nfai_buf_t R, nfai_buf_t C, uint32_t M,

@@ -66,6 +66,7 @@ SIGNATURES = {
     "nfai_hip_gemv": [H, H, i32, H, H, u64, u32, u32],
     "nfai_hip_gemm_f16": [H, H, H, H, H, u32, u32, u32, i32],
     "nfai_hip_gemm_f16_ex": [H, H, H, H, H, H, u32, u32, u32, i32, i32, u32, u32, u32, u32],
+    "nfai_hip_attn_prefill": [H, H, H, H, H, u32, u32, u32, u32, u32, u32],
     "nfai_hip_gemm_kq": [H, H, H, i32, H, H, u32, u32, u32],
     "nfai_hip_rope": [H, H, u64, H, u64, H, u32, u32, u32, u32],
     "nfai_hip_attn_scores": [H, H, H, H, u32, u32, u32, u32],

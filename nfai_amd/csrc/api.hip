@@ -615,6 +615,25 @@ NFAI_API int32_t nfai_hip_gemm_f16(nfai_ctx_t h, nfai_buf_t A, nfai_buf_t W, nfa
     return NFAI_OK;
 }
 
+NFAI_API int32_t nfai_hip_attn_prefill(nfai_ctx_t h, nfai_buf_t Q, nfai_buf_t K, nfai_buf_t Vt, nfai_buf_t O, uint32_t T, uint32_t H, uint32_t Hkv,
+                                       uint32_t D, uint32_t Spad, uint32_t pos0)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(bq, Q);
+    BUF_OR_FAIL(bk, K);
+    BUF_OR_FAIL(bv, Vt);
+    BUF_OR_FAIL(bo, O);
+    if (T == 0 || Hkv == 0 || H % Hkv || (D != 64 && D != 128) || Spad % 32 || (uint64_t)pos0 + T > Spad)
+        return fail(NFAI_ERR_INVALID, "attn_prefill: bad shape (T=%u H=%u Hkv=%u D=%u Spad=%u pos0=%u)", T, H, Hkv, D, Spad, pos0);
+    NEED(bq, (uint64_t)T * H * D, 2);
+    NEED(bk, (uint64_t)Hkv * Spad * D, 2);
+    NEED(bv, (uint64_t)Hkv * Spad * D, 2);
+    NEED(bo, (uint64_t)T * H * D, 2);
+    hipError_t e = launch_attn_prefill(bq->ptr, bk->ptr, bv->ptr, bo->ptr, T, H, Hkv, D, Spad, pos0, c->stream);
+    if (e != hipSuccess) return fail(NFAI_ERR_HIP, "attn_prefill: launch failed: %s", hipGetErrorString(e));
+    return NFAI_OK;
+}
+
 // Extended form of nfai_hip_gemm_f16 for tests and tools: every epilogue (fp32 + residual, fp16, SiLU*up fp16), head-batched
 // operands (batch, b_div) and the causal tile skipping of the attention GEMMs — the configurations the MFMA prefill launches.
 //   A [batch][M][K] fp16;  W [batch / b_div][N][K] fp16 (epi 2: W = gate [N/2][K], W1 = up [N/2][K], batch 1);

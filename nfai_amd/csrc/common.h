@@ -153,6 +153,9 @@ hipError_t launch_rope_store_rows(const float *q, const float *k, const float *v
                                   uint32_t Spad, hipStream_t s);
 hipError_t launch_kv_to_f16(const void *kc, const void *vc, int kv_f16, uint64_t pos_stride, uint64_t head_stride, void *kh, void *vt,
                             uint32_t Hkv, uint32_t D, uint32_t S, uint32_t Spad, uint32_t skip_lo, uint32_t skip_hi, hipStream_t s);
+// causal attention of a prompt chunk in one launch: qh [T][H*D], kh [Hkv][Spad][D], vt [Hkv][D][Spad] (fp16) -> out [T][H*D] fp16
+hipError_t launch_attn_prefill(const void *qh, const void *kh, const void *vt, void *out_f16, uint32_t T, uint32_t H, uint32_t Hkv,
+                               uint32_t D, uint32_t Spad, uint32_t pos0, hipStream_t s);
 hipError_t launch_softmax_causal_rows(const float *sc, void *p_f16, uint32_t H, uint32_t T, uint32_t Spad, uint32_t pos0, float scale,
                                       hipStream_t s);
 hipError_t launch_silu_mul_rows(const float *gate, const float *up, void *act_f16, uint32_t T, uint32_t F, uint32_t ld, hipStream_t s);

@@ -1166,6 +1166,178 @@ hipError_t launch_softmax_causal_rows(const float *sc, void *p_f16, uint32_t H, 
 }
 
 // act = up * silu(gate) over T*F elements, fp16 out (SiLUShader + ElementWiseMultiplicationShader)
+// ---- causal attention of a prompt chunk in one launch (scores, softmax, weighted V: AttentionScoreCalculationShader /
+// AttentionSoftmaxShader / AttentionWeightedValueSumShader for T query rows at once; the reference runs them per token) -----------
+// Replaces Q.K^T GEMM + row softmax + P.V GEMM (25 MB of scores and 12 MB of probabilities per block at T = 512 never exist).
+// Workgroup = 64 query rows of one head, one wave per 16 rows; 32 keys per step:
+//   S^T = K . Q^T    (mfma 16x16x32: A = 16 keys x 32 d, B = the wave's Q rows, held in registers)
+//        -> lane (q, g) holds keys g*4 .. g*4+3 of both 16-key tiles for query q: exactly the eight k-slots of lane group g of a
+//           B fragment if the MFMA's k index is READ as (g, j) -> key g*4 + j (j < 4), 16 + g*4 + (j - 4) (j >= 4);
+//   O^T += V^T . P^T (A = V^T rows d in the same key order: two 8-byte reads per fragment; B = the probabilities, from registers)
+// so the probabilities never leave the registers they were computed in.  The K and V^T tiles of a step (8 KB each at D = 128) go
+// global -> LDS once per workgroup with LDS-DMA (a ring of ATTN_PF_NST stages, counted vmcnt + raw s_barrier as in k_gemm_f16_glds; the swizzle
+// that makes the fragment reads conflict-free is applied to the per-lane SOURCE address) — a first version in which every wave
+// loaded its own fragments from L2 took 49.9 us per launch at 3B, T = 512: bound by what a CU can take in, not by arithmetic.
+// Online softmax per query (running max, rescale), the reference's exp(clamp(s - max, -80, 80)) with the running max and the
+// hardware exponential (v_exp_f32: the probabilities are rounded to fp16 anyway); fp32 accumulation, as the GEMM path.
+#ifndef ATTN_PF_NST
+#define ATTN_PF_NST 3  // stages of the K / V^T ring (measured per launch at 3B, T = 512: 3 stages 22.2 us, 6 stages 22.6 us — the step is
+                       // bound by its dependent chain S-MFMAs -> max -> exp -> P.V-MFMAs with one wave per SIMD, not by the tiles' latency)
+#endif
+template <int D>
+__global__ __launch_bounds__(256) void k_attn_prefill(const _Float16 *QH, const _Float16 *KH, const _Float16 *VT, _Float16 *O, uint32_t T,
+                                                      uint32_t H, uint32_t G, uint32_t Spad, uint32_t pos0, float scale)
+{
+    constexpr int KK = D / 32, DT = D / 16, NST = ATTN_PF_NST;
+    constexpr int KROW = D * 2;                  // bytes of a key row in the K tile (D / 8 chunks of 16 B)
+    constexpr int KCH = D / 8;                   // chunks per key row
+    constexpr int K_BYTES = 32 * KROW, V_BYTES = D * 64, STAGE = K_BYTES + V_BYTES;
+    constexpr int KI = K_BYTES / 1024, VI = V_BYTES / 1024;  // LDS-DMA instructions per tile (1 KiB each)
+    static_assert(KI % 4 == 0 && VI % 4 == 0, "instructions divide over the four waves");
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t qi = lane & 15, g = lane >> 4;
+    const uint32_t qblocks = (T + 63) / 64;
+    const uint32_t qb = qblocks - 1 - blockIdx.x;  // long rows first
+    const uint32_t q0 = (qb * 4 + wave) * 16;
+    const uint32_t h = blockIdx.y, kvh = h / G, HD = H * D;
+    const uint32_t qrow = min(q0 + qi, T - 1);
+    f16x8 qf[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++)
+        qf[kk] = *reinterpret_cast<const GLOBAL_AS f16x8 *>((const GLOBAL_AS _Float16 *)QH + (uint64_t)qrow * HD + h * D + kk * 32 + g * 8);
+    const GLOBAL_AS uint8_t *Kb = (const GLOBAL_AS uint8_t *)(KH + (uint64_t)kvh * Spad * D);
+    const GLOBAL_AS uint8_t *Vb = (const GLOBAL_AS uint8_t *)(VT + (uint64_t)kvh * D * Spad);
+    const uint32_t kmax = pos0 + min(qb * 64 + 63, T - 1) + 1;  // keys the workgroup's last row can see (exclusive)
+    const uint32_t nsteps = (kmax + 31) / 32;                   // block-uniform
+    const uint32_t my_last = pos0 + q0 + qi;                    // last key of this lane's query
+
+    // per-lane source offsets of this wave's LDS-DMA instructions (K: 4 keys per instruction, V^T: 16 d rows per instruction)
+    static_assert(KI / 4 <= 2 && VI / 4 <= 2, "source offset arrays");
+    uint32_t ksrc[2], vsrc[2];  // fixed bounds: with template-dependent bounds captured by a lambda the host pass of hipcc 7.2 drops the kernel's definition
+#pragma unroll
+    for (int i = 0; i < KI / 4; i++) {
+        const uint32_t ins = i * 4 + wave, key = ins * (1024 / KROW) + lane / KCH, c = lane % KCH;
+        ksrc[i] = key * KROW + ((c ^ (key & (KCH - 1) & 15)) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < VI / 4; i++) {
+        const uint32_t ins = i * 4 + wave, dd = ins * 16 + lane / 4, c = lane % 4;
+        vsrc[i] = dd * Spad * 2 + ((c ^ ((dd >> 2) & 3)) * 16);
+    }
+    auto issue = [&](uint32_t st, uint32_t stage) {
+        const uint32_t k0 = min(st, nsteps - 1) * 32;
+#pragma unroll
+        for (int i = 0; i < KI / 4; i++)
+            __builtin_amdgcn_global_load_lds(Kb + (uint64_t)k0 * KROW + ksrc[i], (lds_u8 *)(lds + stage * STAGE + (i * 4 + wave) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < VI / 4; i++)
+            __builtin_amdgcn_global_load_lds(Vb + (uint64_t)k0 * 2 + vsrc[i], (lds_u8 *)(lds + stage * STAGE + K_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+    };
+    f32x4 acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = -1.0e38f, l = 0.f;
+    typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int s2 = 0; s2 < NST - 1; s2++) issue(s2, s2);
+    uint32_t cur = 0, fill = NST - 1;
+    for (uint32_t st = 0; st < nsteps; st++) {
+        wait_vmcnt<(KI / 4 + VI / 4) * (NST - 2)>();
+        __builtin_amdgcn_s_barrier();
+        issue(st + NST - 1, fill);
+        const uint8_t *lk = lds + cur * STAGE, *lv = lk + K_BYTES;
+        const uint32_t k0 = st * 32;
+        f32x4 sc[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++) {
+            sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const uint32_t key = kt * 16 + qi;
+#pragma unroll
+            for (int kk = 0; kk < KK; kk++) {
+                const f16x8 kf = *reinterpret_cast<const f16x8 *>(lk + key * KROW + (((kk * 4 + g) ^ (key & (KCH - 1) & 15)) * 16));
+                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kk], sc[kt], 0, 0, 0);
+            }
+        }
+        float mx = m;
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t key = k0 + kt * 16 + g * 4 + r;
+                sc[kt][r] = key <= my_last ? sc[kt][r] * scale : -1.0e38f;
+                mx = fmaxf(mx, sc[kt][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float corr = __expf(fmaxf(m - mx, -80.f));  // 1 when nothing changes; e^-80 ~ 0 while nothing has been seen (acc and l are 0 then)
+        f16x8 pf;
+        float ls = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t key = k0 + kt * 16 + g * 4 + r;
+                const float e = key <= my_last ? __expf(fminf(fmaxf(sc[kt][r] - mx, -80.f), 80.f)) : 0.f;  // AttentionSoftmaxShader.cs:160-166
+                const _Float16 eh = (_Float16)e;
+                pf[kt * 4 + r] = eh;
+                ls += (float)eh;  // the sum of what is actually multiplied
+            }
+        l = l * corr + ls;
+        m = mx;
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) {
+            acc[dt] *= corr;
+            const uint32_t dd = dt * 16 + qi, sw = (dd >> 2) & 3;
+            const f16x4v v0 = *reinterpret_cast<const f16x4v *>(lv + dd * 64 + (((g >> 1) ^ sw) * 16) + (g & 1) * 8);
+            const f16x4v v1 = *reinterpret_cast<const f16x4v *>(lv + dd * 64 + (((2 + (g >> 1)) ^ sw) * 16) + (g & 1) * 8);
+            f16x8 va;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { va[e] = v0[e]; va[4 + e] = v1[e]; }
+            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pf, acc[dt], 0, 0, 0);
+        }
+        cur = cur + 1 == NST ? 0 : cur + 1;
+        fill = fill + 1 == NST ? 0 : fill + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus DMAs of the last iterations must not outlive the workgroup's LDS
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    if (q0 + qi < T) {
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) {
+            f16x4v o;
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[r] = (_Float16)(acc[dt][r] * inv);
+            *reinterpret_cast<f16x4v *>(O + (uint64_t)(q0 + qi) * HD + h * D + dt * 16 + g * 4) = o;
+        }
+    }
+}
+
+hipError_t launch_attn_prefill(const void *qh, const void *kh, const void *vt, void *out_f16, uint32_t T, uint32_t H, uint32_t Hkv,
+                               uint32_t D, uint32_t Spad, uint32_t pos0, hipStream_t s)
+{
+    if (T == 0) return hipSuccess;
+    if (Hkv == 0 || H % Hkv || Spad % 32 || pos0 + T > Spad || (D != 64 && D != 128)) return hipErrorInvalidValue;
+    const dim3 grid((T + 63) / 64, H);
+    const float scale = 1.0f / sqrtf((float)D);  // AttentionScoreCalculationShader.cs:93
+    const size_t lds = (size_t)ATTN_PF_NST * (32 * D * 2 + D * 64);
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn_prefill<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (D == 128)
+        k_attn_prefill<128><<<grid, 256, lds, s>>>(static_cast<const _Float16 *>(qh), static_cast<const _Float16 *>(kh),
+                                                   static_cast<const _Float16 *>(vt), static_cast<_Float16 *>(out_f16), T, H, H / Hkv, Spad, pos0, scale);
+    else
+        k_attn_prefill<64><<<grid, 256, lds, s>>>(static_cast<const _Float16 *>(qh), static_cast<const _Float16 *>(kh),
+                                                  static_cast<const _Float16 *>(vt), static_cast<_Float16 *>(out_f16), T, H, H / Hkv, Spad, pos0, scale);
+    return hipGetLastError();
+}
+
 __global__ void k_silu_mul_rows(const float *gate, const float *up, _Float16 *act, uint64_t n, uint32_t F, uint32_t ld)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

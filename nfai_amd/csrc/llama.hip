@@ -1033,24 +1033,31 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
                                      m->d_freqs, d.rope_dims, d.H, d.Hkv, d.D, pos0, T, QKV, w.KH, w.VT, Spad, s));
         // earlier positions (chunked prompts) and the zero padding; the chunk's own rows were written above
         P_TRY(launch_kv_to_f16(L.kcache, L.vcache, kvf16, m->kv_pos_stride, m->kv_head_stride, w.KH, w.VT, d.Hkv, d.D, S, Spad, pos0, S, s));
-        {   // scores[h][t][s] = q_h[t] . k_kvh[s]   (scaling and the causal limit are applied by the softmax)
-            GemmArgs g;
-            g.A = w.QH; g.lda = HD; g.a_bs = d.D;
-            g.B = w.KH; g.ldb = d.D; g.b_bs = (uint64_t)Spad * d.D; g.b_div = G;
-            g.C = w.SC; g.ldc = Spad; g.c_bs = (uint64_t)T * Spad;
-            g.M = T; g.N = Spad; g.K = d.D; g.batch = d.H;
-            g.causal = 1; g.causal_pos0 = pos0;
-            P_TRY(launch_gemm_f16(g, s));
-        }
-        P_TRY(launch_softmax_causal_rows(w.SC, w.P, d.H, T, Spad, pos0, 1.0f / sqrtf((float)d.D), s));
-        {   // att[t][h*D + d] = sum_s P[h][t][s] * V_kvh[s][d]
-            GemmArgs g;
-            g.A = w.P; g.lda = Spad; g.a_bs = (uint64_t)T * Spad;
-            g.B = w.VT; g.ldb = Spad; g.b_bs = (uint64_t)d.D * Spad; g.b_div = G;
-            g.C = w.XN; g.epi = 1; g.ldc = HD; g.c_bs = d.D;   // fp16 straight into the Wo GEMM's A operand
-            g.M = T; g.N = d.D; g.K = Spad; g.batch = d.H;
-            g.causal = 2; g.causal_pos0 = pos0;
-            P_TRY(launch_gemm_f16(g, s));
+        // attention of the chunk.  Default: one launch (k_attn_prefill: scores, causal softmax and weighted V with the probabilities
+        // kept in registers); NFAI_PREFILL_FLASH=0: Q.K^T GEMM -> row softmax -> P.V GEMM with materialised scores.
+        static const bool flash = !(getenv("NFAI_PREFILL_FLASH") && atoi(getenv("NFAI_PREFILL_FLASH")) == 0);
+        if (flash) {
+            P_TRY(launch_attn_prefill(w.QH, w.KH, w.VT, w.XN, T, d.H, d.Hkv, d.D, Spad, pos0, s));
+        } else {
+            {   // scores[h][t][s] = q_h[t] . k_kvh[s]   (scaling and the causal limit are applied by the softmax)
+                GemmArgs g;
+                g.A = w.QH; g.lda = HD; g.a_bs = d.D;
+                g.B = w.KH; g.ldb = d.D; g.b_bs = (uint64_t)Spad * d.D; g.b_div = G;
+                g.C = w.SC; g.ldc = Spad; g.c_bs = (uint64_t)T * Spad;
+                g.M = T; g.N = Spad; g.K = d.D; g.batch = d.H;
+                g.causal = 1; g.causal_pos0 = pos0;
+                P_TRY(launch_gemm_f16(g, s));
+            }
+            P_TRY(launch_softmax_causal_rows(w.SC, w.P, d.H, T, Spad, pos0, 1.0f / sqrtf((float)d.D), s));
+            {   // att[t][h*D + d] = sum_s P[h][t][s] * V_kvh[s][d]
+                GemmArgs g;
+                g.A = w.P; g.lda = Spad; g.a_bs = (uint64_t)T * Spad;
+                g.B = w.VT; g.ldb = Spad; g.b_bs = (uint64_t)d.D * Spad; g.b_div = G;
+                g.C = w.XN; g.epi = 1; g.ldc = HD; g.c_bs = d.D;   // fp16 straight into the Wo GEMM's A operand
+                g.M = T; g.N = d.D; g.K = Spad; g.batch = d.H;
+                g.causal = 2; g.causal_pos0 = pos0;
+                P_TRY(launch_gemm_f16(g, s));
+            }
         }
         P_TRY(gemm(w.XN, HD, L.wo, nullptr, nullptr, w.H1, w.X, d.E, HD));                 // + residual (TransformerBlock.cs:153-158)
         P_TRY(launch_rmsnorm_rows(w.H1, static_cast<const float *>(L.ffn_norm.ptr), w.XN, T, d.E, d.eps, s));

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -136,8 +137,9 @@ def run_schedule_in_process(stages, n_steps: int, first_tokens, copy):
 class TorchComm:
     """torch.distributed point-to-point; one batch per tick (ncclGroupStart/End under RCCL)."""
 
-    def __init__(self, dist, stage_through_host: bool = False):
+    def __init__(self, dist, stage_through_host: bool = False, group=None):
         self.dist = dist
+        self.group = group  # None: the default process group
         # gloo cannot move device tensors point-to-point: the single-GPU-box rehearsal of the
         # multi-rank path (two ranks sharing one card, backend gloo) bounces through host copies
         self.host = stage_through_host
@@ -159,7 +161,8 @@ class TorchComm:
         key = (tuple((t.data_ptr(), dst) for t, dst in sends), tuple((t.data_ptr(), src) for t, src in recvs))
         ops = self._ops.get(key)
         if ops is None:
-            ops = [d.P2POp(d.isend, t, dst) for t, dst in sends] + [d.P2POp(d.irecv, t, src) for t, src in recvs]
+            ops = ([d.P2POp(d.isend, t, dst, group=self.group) for t, dst in sends]
+                   + [d.P2POp(d.irecv, t, src, group=self.group) for t, src in recvs])
             self._ops[key] = ops
         for w in d.batch_isend_irecv(ops):
             w.wait()
@@ -306,9 +309,28 @@ def run_bench_pipeline(args):
         mgr = HipBufferManager(local, stream=stream.cuda_stream)
         stage = HipStage(torch, mgr, dims, (lb, le), weights, world, C, rank, world, kv_f16=args.kv_f16, graph=not args.no_graph)
         if use_cabi:
-            box = [RcclComm.unique_id() if rank == 0 else None]
+            # every rank learns whether ALL ranks got their communicator (a rank that failed must not leave the others in a
+            # collective): if not, the exchange falls back to torch.distributed's own NCCL binding and the line says so
+            comm, why = None, ""
+            try:
+                box = [RcclComm.unique_id() if rank == 0 else None]
+            except Exception as e:  # noqa: BLE001 - reported below, the run continues on the torch binding
+                box, why = [None], repr(e)
             dist.broadcast_object_list(box, src=0)
-            comm = RcclComm(mgr, rank, world, box[0])
+            if box[0] is not None:
+                try:
+                    comm = RcclComm(mgr, rank, world, box[0])
+                except Exception as e:  # noqa: BLE001
+                    why = repr(e)
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                print(f"[rank {rank}] nfai_hip_pp_* communicator not available on every rank ({why or 'another rank failed'}): "
+                      "exchange through torch.distributed (nccl)", file=sys.stderr, flush=True)
+                use_cabi = False
+                comm = TorchComm(dist, group=dist.new_group(backend="nccl"))
         else:
             comm = TorchComm(dist, stage_through_host=rehearsal)
         toks =[(128000 + 17 * s) % dims.V for s in range(world)]

@@ -418,6 +418,46 @@ def test_gemm_f16_odd_tile_widths(mgr, variant, M, N, K, res):
     assert np.abs(got - want).max() <= 2e-6 * np.sqrt(K) * scale + 1e-5, np.abs(got - want).max()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,Hkv,D,T,pos0", [(24, 8, 128, 512, 0), (32, 8, 64, 200, 0), (4, 2, 128, 37, 64), (32, 8, 128, 130, 126), (2, 2, 64, 16, 0)],
+                         ids=["3b-512", "1b-200-ragged", "tiny-chunk2", "8b-chunk-at-126", "one-tile"])
+def test_attn_prefill_one_launch(mgr, H, Hkv, D, T, pos0):
+    """Causal attention of a prompt chunk in one launch (k_attn_prefill: K.Q^T and V^T.P^T on the matrix cores, probabilities
+    kept in registers, online softmax) against fp64 NumPy on the same fp16 operands: query t sees keys 0..pos0+t, softmax of
+    q.k/sqrt(D) (AttentionScoreCalculationShader.cs:93, AttentionSoftmaxShader.cs:148-176), weighted sum of V.  The
+    probabilities are rounded to fp16 before they multiply V (as in the GEMM path): |d| <= 2e-3 * max|V| + fp16 output rounding."""
+    from nfai_amd._lib import NfaiHipError, call
+    from nfai_amd.hip import ShaderProperty
+    r = rng(900 + T + pos0)
+    S = pos0 + T
+    Spad = (S + 63) // 64 * 64
+    G = H // Hkv
+    Q = r.standard_normal((T, H, D)).astype(np.float16)
+    K = np.zeros((Hkv, Spad, D), np.float16)
+    V = np.zeros((Hkv, Spad, D), np.float16)
+    K[:, :S] = r.standard_normal((Hkv, S, D)).astype(np.float16)
+    V[:, :S] = r.standard_normal((Hkv, S, D)).astype(np.float16)
+    Vt = np.ascontiguousarray(V.transpose(0, 2, 1))
+    pq, pk = ShaderProperty(mgr, Q.size, np.float16), ShaderProperty(mgr, K.size, np.float16)
+    pv, po = ShaderProperty(mgr, Vt.size, np.float16), ShaderProperty(mgr, Q.size, np.float16)
+    pq.SetValue(Q.ravel()); pk.SetValue(K.ravel()); pv.SetValue(Vt.ravel())
+    call("nfai_hip_attn_prefill", mgr.handle, pq.handle, pk.handle, pv.handle, po.handle, T, H, Hkv, D, Spad, pos0)
+    got = po.GetValue().reshape(T, H, D).astype(np.float64)
+    want = np.zeros((T, H, D))
+    q64, k64, v64 = Q.astype(np.float64), K.astype(np.float64), V.astype(np.float64)
+    for h in range(H):
+        sc = q64[:, h] @ k64[h // G, :S].T / np.sqrt(D)          # [T][S]
+        mask = np.arange(S)[None, :] <= (pos0 + np.arange(T))[:, None]
+        sc = np.where(mask, sc, -np.inf)
+        p = np.exp(sc - sc.max(axis=1, keepdims=True))
+        p /= p.sum(axis=1, keepdims=True)
+        want[:, h] = p @ v64[h // G, :S]
+    tol = 2e-3 * float(np.abs(v64).max()) + 2e-3 * np.abs(want).max()
+    assert np.abs(got - want).max() <= tol, (np.abs(got - want).max(), tol)
+    with pytest.raises(NfaiHipError, match="bad shape"):
+        call("nfai_hip_attn_prefill", mgr.handle, pq.handle, pk.handle, pv.handle, po.handle, T, H, Hkv, D, Spad, Spad)  # pos0 + T > Spad
+
+
 def _silu64(x):
     return x / (1.0 + np.exp(-x))
 
