@@ -43,6 +43,7 @@ struct GemmParams {
                                  // (the softmax never reads them).  2: A = probabilities [t][s]: K tiles past the last
                                  // unmasked key of the tile's rows are skipped (they multiply zeros).
     uint32_t causal_pos0;
+    NFAI_STAMP_PARAM
     uint32_t ksplit;             // > 1: blockIdx.z owns K tiles [z*KT/ksplit, (z+1)*KT/ksplit) and adds its product atomically
                                  // into C, which the host has initialised with the residual (or zeros)
 };
@@ -659,7 +660,17 @@ __global__ __launch_bounds__(256) void k_gemm_f16_glds(const GemmParams p)
 
     uint32_t cur = 0, fill = NST - 1;     // A: stage being multiplied, stage being refilled
     uint32_t curb = 0, fillb = NSTB - 1;  // B likewise
+#ifdef NFAI_STAMPS
+    // diagnostic build: shader-clock cycles this wave spends waiting for its tile (vmcnt), at the barrier, issuing, multiplying
+    STAMP_DECL;
+    unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_mul = 0, c0 = __builtin_amdgcn_s_memtime(), c1;
+    const unsigned long long c_start = c0;
+#define GEMM_TICK(acc_) do { __builtin_amdgcn_sched_barrier(0); c1 = __builtin_amdgcn_s_memtime(); acc_ += c1 - c0; c0 = c1; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define GEMM_TICK(acc_) ((void)0)
+#endif
     for (uint32_t kt = 0; kt < KT; kt++) {
+        GEMM_TICK(c_mul);
         if constexpr (ROLES) {
             if (role_a) wait_vmcnt<AG * (NST - 2)>();
             else wait_vmcnt<BG * (NSTB - 2)>();
@@ -667,9 +678,12 @@ __global__ __launch_bounds__(256) void k_gemm_f16_glds(const GemmParams p)
             if (b_last) wait_vmcnt<(AG + BG) * (NST - 2)>();
             else wait_vmcnt<(AG + BG - 1) * (NST - 2)>();
         }
+        GEMM_TICK(c_wait);
         __builtin_amdgcn_s_barrier();
+        GEMM_TICK(c_bar);
         if (role_a) issue_a(min(kt + NST - 1, KT - 1), fill);
         if (role_b) issue_b(min(kt + NSTB - 1, KT - 1), fillb);
+        GEMM_TICK(c_issue);
         const uint8_t *la = lds + cur * A_BYTES, *lb = lds + B_BASE + curb * B_BYTES;
         constexpr int KSTEPS = BK / 32;
         auto load_frags = [&](int ks, f16x8 (&a)[TM], f16x8 (&b)[TN]) {
@@ -722,8 +736,16 @@ __global__ __launch_bounds__(256) void k_gemm_f16_glds(const GemmParams p)
         curb = curb + 1 == NSTB ? 0 : curb + 1;
         fillb = fillb + 1 == NSTB ? 0 : fillb + 1;
     }
+    GEMM_TICK(c_mul);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus DMAs of the last iterations must not outlive the workgroup's LDS
     gemm_store<BM, BN, WM, WN, EPI, TM, TN>(acc, p, m0, n0, wm, wn, lane, batch);
+#ifdef NFAI_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GEMM_TICK(c_issue);  // epilogue counted with the issue bucket's neighbour below
+    _st.t[0] = c_start; _st.t[1] = c_wait; _st.t[2] = c_bar; _st.t[3] = c_issue; _st.t[4] = c_mul; _st.t[5] = c1; _st.t[6] = KT;
+    STAMP_FLUSH(p.stamps, blockIdx.x * 4 + wave, 7);
+#endif
+#undef GEMM_TICK
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, int NST, int BK = 64, bool PIPE = false, int NSTB = NST>
@@ -740,7 +762,9 @@ static hipError_t gemm_launch_glds(const GemmParams &p, uint32_t batch, hipStrea
         attr_set = true;
     }
     const uint32_t tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles, batch, 1), dim3(256), LDS, s, p);
+    GemmParams pp = p;
+    NFAI_STAMP_SET(pp, "gemm_glds", tiles, 256);
+    hipLaunchKernelGGL(kern, dim3(tiles, batch, 1), dim3(256), LDS, s, pp);
     return hipGetLastError();
 }
 
