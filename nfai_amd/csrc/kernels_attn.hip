@@ -726,7 +726,9 @@ static hipError_t fill_params(const AttnArgs &a, AttnParams &p, dim3 &grid, size
     p.partials = a.partials + 64;
     p.H = a.H; p.Hkv = a.Hkv; p.D = a.D; p.pos = a.pos_dev;
     static const int env_poll = getenv("NFAI_ATTN_POLL") ? atoi(getenv("NFAI_ATTN_POLL")) : 1;  // 0: ticket hand-off everywhere (A/B runs)
-    p.epoch = env_poll ? a.epoch : nullptr;
+    // granule hand-off: the slices' workgroups poll each other, so all Hkv x slices of them must be resident at once (four
+    // 256-thread workgroups fit a CU); on a smaller device (a partition) the ticket form, which never waits, is used
+    p.epoch = (env_poll && (uint64_t)a.n_cu * 4 >= (uint64_t)a.Hkv * ATTN_NSPLIT_MAX) ? a.epoch : nullptr;
     p.tag_mul = a.tag_mul; p.tag_add = a.tag_add; p.err = a.err;
     static const int env_mc = getenv("NFAI_ATTN_MIN_CHUNK") ? atoi(getenv("NFAI_ATTN_MIN_CHUNK")) : 0;
     static const int env_ms = getenv("NFAI_ATTN_MAX_SPLIT") ? atoi(getenv("NFAI_ATTN_MAX_SPLIT")) : 0;
@@ -786,6 +788,8 @@ static bool attn_wo_plan(const AttnArgs &a, const GemvArgs &g, uint32_t &nbw, At
     static const int env_poll = getenv("NFAI_ATTN_POLL") ? atoi(getenv("NFAI_ATTN_POLL")) : 1;
     static const int env_online = getenv("NFAI_ATTN_ONLINE") ? atoi(getenv("NFAI_ATTN_ONLINE")) : -1;
     if (!env || !env_poll || env_online == 1 || !a.epoch || a.C > 2048) return false;
+    // the slices' workgroups wait for each other: all of them must be resident at once, and this launch holds one per CU
+    if (a.n_cu < a.Hkv * ATTN_NSPLIT_MAX) return false;
     if (g.mode != GEMV_RESIDUAL || g.gamma || !g.res || g.x != a.o) return false;
     if (a.Hkv == 0 || a.H % a.Hkv || (a.D != 64 && a.D != 128)) return false;
     const uint32_t HD = a.H * a.D, E = g.seg_rows[0];
