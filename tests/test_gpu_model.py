@@ -221,18 +221,20 @@ def test_one_full_width_block(mgr, dims):
     m.Dispose()
 
 
-@pytest.mark.parametrize("dims,n_pos", [(synth.LLAMA_32_1B, 1100), (synth.LLAMA_32_3B, 200), (synth.LLAMA_31_8B, 200)],
-                         ids=["1b-1100", "3b-200", "8b-200"])
-def test_attention_slices_full_width(mgr, dims, n_pos):
+@pytest.mark.parametrize("dims,n_pos,cap", [(synth.LLAMA_32_1B, 1100, 0), (synth.LLAMA_32_3B, 200, 0), (synth.LLAMA_31_8B, 200, 0),
+                                            (synth.LLAMA_32_3B, 700, 2304)],
+                         ids=["1b-1100", "3b-200", "8b-200", "3b-700-long-capacity"])
+def test_attention_slices_full_width(mgr, dims, n_pos, cap):
     """The KV slices of the decode attention and their hand-off inside the launch ({value, tag} granules polled by the block of
     the last slice; tag = token epoch x blocks + block) at the head shapes of the BASELINE models: two blocks (two tags per
     token on one workspace), every position from 1 slice to the maximum of 32 (1B: 1100 positions), logits against the oracle
-    at every step."""
+    at every step.  A KV capacity above 2048 selects the one-pass (online softmax) form of the kernel and two launches
+    (attention, then Wo) instead of the fused one: same hand-off, same tolerance."""
     from dataclasses import replace
     from nfai_amd.llama_model import LlamaModel
     d2 = replace(dims, L=2, V=1024, name=dims.name + "-2blk")
     w = synth.make_weights(d2, seed=37)
-    C = n_pos + 4
+    C = cap or n_pos + 4
     m = LlamaModel(mgr, synth.make_metadata(d2), w, C)
     ref = orc.OracleLlama(odesc(d2, C), w)
     worst = 0.0
