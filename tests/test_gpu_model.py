@@ -135,9 +135,9 @@ def test_kv_f16_option(mgr):
     from nfai_amd.llama_model import LlamaModel
     dims = synth.TINY_D128
     w = synth.make_weights(dims, seed=25, std=0.05)
-    m = LlamaModel(mgr, synth.make_metadata(dims), w, 32, kv_f16=True)
-    ref = orc.OracleLlama(odesc(dims, 32), w)
-    for t in synth.make_tokens(dims, 24, seed=6):
+    m = LlamaModel(mgr, synth.make_metadata(dims), w, 128, kv_f16=True)
+    ref = orc.OracleLlama(odesc(dims, 128), w)
+    for t in synth.make_tokens(dims, 100, seed=6):  # up to four KV slices: the fp16-KV form of the fused attention + Wo launch
         lg, am = m.Step(int(t))
         want = ref.step(int(t))
         assert np.abs(lg - want).max() <= logit_tol(want, 2e-2)
