@@ -11,13 +11,17 @@
 //    covers 64/(D/4) positions per load instruction; the first four K rows AND the first four V rows
 //    of every lane group are requested before any arithmetic (V does not depend on the scores).
 //  - the scores of the slice stay in LDS between the phases.
-//  - the slices are merged in the SAME launch by the last block of each kv head to finish
-//    (log-sum-exp merge == the reference softmax up to rounding; its clamp(s - max, -80, 80) only
-//    alters terms below e^-80).  Hand-off: every partial word is stored write-through at agent
-//    scope, each storing wave drains its stores, the block's barrier, ONE lane takes a ticket with an
-//    agent-scope atomic; the block whose ticket is last reads the partials with agent-scope loads
-//    after its own barrier (MI355X guide, visibility table row 1).  No result depends on which block
-//    is last: the merge order over slices is fixed (0..nsplit-1), so runs are bit-reproducible.
+//  - the slices are merged in the SAME launch (log-sum-exp merge == the reference softmax up to rounding; its
+//    clamp(s - max, -80, 80) only alters terms below e^-80), in fixed slice order 0..nsplit-1, so runs are bit-reproducible
+//    and no result depends on which block finishes last.  Two hand-off forms:
+//      POLL (the model path): every block publishes its sums and (max, sum of exp) as 8-byte {value, tag} granules (sc1
+//        stores; tag = per-token epoch x blocks + block) and merges ITS share of the kv head's outputs after polling the
+//        other slices' granules with sc1 loads — no drain, no ticket, no re-arm (MI355X guide, valid hand-off forms);
+//      ticket (the op-level entry, small devices, NFAI_ATTN_POLL=0): every partial word is stored write-through, each storing
+//        wave drains its stores, the block's barrier, ONE lane takes a ticket with an agent-scope atomic; the block whose
+//        ticket is last reloads the partials and merges (guide, visibility table row 1).
+//  - k_attn_wo (below): the same program in four waves of a workgroup whose other four waves stream Wo into registers
+//    meanwhile and apply it to the merged output: attention + Wo + residual in one launch.
 // The number of ACTIVE slices depends on the sequence length, which is read from device memory so
 // a captured hipGraph can be replayed for every position; inactive blocks exit at once.
 #include <stdlib.h>
