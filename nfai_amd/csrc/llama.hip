@@ -680,6 +680,7 @@ NFAI_API int32_t nfai_hip_llama_create(nfai_ctx_t ch, const nfai_llama_desc *des
         DALLOC(m->up, d.F * 4);
     }
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&m->h_pin), 4096, hipHostMallocDefault));
+    memset(m->h_pin, 0, 4096);
     if (d.max_batch > 0 && !m->unfused) {
         Model::Prefill &w = m->pf;
         w.T = (d.max_batch + 127) / 128 * 128;
@@ -1161,6 +1162,10 @@ static int stage_enqueue(Model *m, const void *hidden_in, void *hidden_out)
     int rc = enqueue_token(m, true);
     if (rc) return rc;
     if (!m->last_stage) HIP_TRY(hipMemcpyAsync(hidden_out, m->x_last ? m->x_last : m->x, (size_t)m->d.E * 4, hipMemcpyDeviceToDevice, s));
+    // the sticky error word of the launches that wait inside the kernel (attention slices, engine) travels to pinned host memory
+    // with every step; nfai_hip_llama_stage_step looks at it on entry, so a stage that never synchronises still reports a
+    // hand-off that gave up — one step late
+    HIP_TRY(hipMemcpyAsync(m->h_pin + 1, m->d_engerr, 4, hipMemcpyDeviceToHost, s));
     return NFAI_OK;
 }
 
@@ -1171,6 +1176,7 @@ NFAI_API int32_t nfai_hip_llama_stage_step(nfai_model_t h, uint32_t token, const
     NEED_FINAL(m);
     hipStream_t s = m->ctx->stream;
     if (m->pos_host >= m->d.C) return fail(NFAI_ERR_KV_FULL, "stage_step: KV cache full at position %u", m->pos_host);
+    if (m->h_pin[1]) return engine_failed(m, m->h_pin[1]);  // written by an earlier step of this stage (see stage_enqueue)
     if (m->first_stage) {
         if (token != NFAI_TOKEN_ON_DEVICE) {
             if (token >= m->d.V) return fail(NFAI_ERR_INVALID, "stage_step: token %u >= vocab %u", token, m->d.V);
@@ -1238,6 +1244,7 @@ NFAI_API int32_t nfai_hip_llama_set_pos(nfai_model_t h, uint32_t pos)
     HIP_TRY(hipMemcpyAsync(m->d_pos, &pos, 4, hipMemcpyHostToDevice, m->ctx->stream));
     HIP_TRY(hipMemsetAsync(m->d_engerr, 0, 4, m->ctx->stream));
     HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    m->h_pin[1] = 0;  // the host mirror of the error word (after the stream is idle: no copy into it is pending)
     m->pos_host = pos;
     return NFAI_OK;
 }
