@@ -268,8 +268,10 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
     // unconditional (row indices are clamped to valid rows): a branch around the issue would make the
     // compiler's vmcnt bookkeeping take the worst path and wait for the weights before using x
     issue(bufA);
+#ifdef GEMV_B_EARLY
     issue(bufB);
-    STAMP(1);  // activation loads and the first two weight steps issued
+#endif
+    STAMP(1);  // activation loads and the first weight step issued
 
     // ---- (3) prologue: x (optionally RMSNorm'd: RMSNormShader.cs:136-149) -> LDS ---------------
     {
@@ -305,7 +307,14 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
         }
         __syncthreads();
     }
-    STAMP(2);  // x (normalised) is in LDS
+    // The second step's requests go out AFTER the prologue: a wave issues in order, and pushing two steps into the CU's memory
+    // queue takes 2.8-3.4 us (tools/stamps.py) during which x — long arrived — is not looked at.  With one step ahead of the
+    // prologue the first FMA comes ~1 us earlier and the second step's requests overlap it (3B fp16: 637 -> 642 tokens/s, the
+    // q|k|v launch 11.8 -> 11.3 us in eager timing; -DGEMV_B_EARLY restores the old order).
+#ifndef GEMV_B_EARLY
+    issue(bufB);
+#endif
+    STAMP(2);  // x (normalised) is in LDS, second weight step issued
 
     float acc[R];
 #pragma unroll
