@@ -395,7 +395,7 @@ struct GemvPlan {
     uint32_t grid, block, lds_bytes;
 };
 
-static GemvPlan plan_gemv(uint32_t NU, uint32_t K, int epl, int rpu, uint32_t n_cu, bool norm)
+static GemvPlan plan_gemv(uint32_t NU, uint32_t K, int epl, int rpu, uint32_t n_cu, bool norm, int mode)
 {
     GemvPlan pl{};
     pl.ok = true;
@@ -419,7 +419,14 @@ static GemvPlan plan_gemv(uint32_t NU, uint32_t K, int epl, int rpu, uint32_t n_
     static const int env_wpb = getenv("NFAI_GEMV_WPB") ? atoi(getenv("NFAI_GEMV_WPB")) : 0;
     static const int env_maxld = getenv("NFAI_GEMV_MAXLD") ? atoi(getenv("NFAI_GEMV_MAXLD")) : 16;
     if (env_wpb >= 1 && env_wpb <= 8 && NU >= n_cu * 8) wpb = (uint32_t)env_wpb;
-    if (env_bpc >= 1 && env_bpc <= 4 && NU >= n_cu * 8) grid = n_cu * (uint32_t)env_bpc;
+    // workgroups per CU by epilogue mode (NFAI_GEMV_BPC_<MODE> overrides one mode, NFAI_GEMV_BPC all)
+    static const int env_bpc_mode[4] = {getenv("NFAI_GEMV_BPC_PLAIN") ? atoi(getenv("NFAI_GEMV_BPC_PLAIN")) : 0,
+                                        getenv("NFAI_GEMV_BPC_RES") ? atoi(getenv("NFAI_GEMV_BPC_RES")) : 0,
+                                        getenv("NFAI_GEMV_BPC_QKV") ? atoi(getenv("NFAI_GEMV_BPC_QKV")) : 0,
+                                        getenv("NFAI_GEMV_BPC_GATEUP") ? atoi(getenv("NFAI_GEMV_BPC_GATEUP")) : 0};
+    static const int def_bpc_mode[4] = {1, 1, 2, 2};  // measured at 3B fp16 (tokens/s): all 1: 642; q|k|v 2: 651; + gate|up 2: 653.5; q|k|v 3: 610; Wdown 2: slower
+    int bpc = env_bpc ? env_bpc : (env_bpc_mode[mode & 3] ? env_bpc_mode[mode & 3] : def_bpc_mode[mode & 3]);
+    if (bpc >= 1 && bpc <= 4 && NU >= n_cu * 8) grid = n_cu * (uint32_t)bpc;
     const uint32_t upw_total = (NU + grid * wpb - 1) / (grid * wpb);  // units per wave (max)
     // units per step: rows_in_flight * u <= 16 loads per lane per step (x2 for the register double
     // buffer = 128 VGPRs), and divide upw_total if we can
@@ -526,7 +533,7 @@ hipError_t launch_gemv(const GemvArgs &a, hipStream_t s)
     p.pos = a.pos_dev;
     p.kv_f16 = a.kv_type == NFAI_F16;
     p.prefetch_only = a.prefetch_only ? 1u : 0u;
-    const GemvPlan pl = plan_gemv(p.NU, a.K, epl, rpu, a.n_cu, a.gamma != nullptr);
+    const GemvPlan pl = plan_gemv(p.NU, a.K, epl, rpu, a.n_cu, a.gamma != nullptr, a.mode);
     if (!pl.ok) return hipErrorInvalidValue;
     p.KC = (a.K + 64 * epl - 1) / (64 * epl);
     if (pl.lds_bytes > 160 * 1024) return hipErrorInvalidValue;
