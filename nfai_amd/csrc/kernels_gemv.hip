@@ -418,7 +418,12 @@ static GemvPlan plan_gemv(uint32_t NU, uint32_t K, int epl, int rpu, uint32_t n_
     static const int env_bpc = getenv("NFAI_GEMV_BPC") ? atoi(getenv("NFAI_GEMV_BPC")) : 0;
     static const int env_wpb = getenv("NFAI_GEMV_WPB") ? atoi(getenv("NFAI_GEMV_WPB")) : 0;
     static const int env_maxld = getenv("NFAI_GEMV_MAXLD") ? atoi(getenv("NFAI_GEMV_MAXLD")) : 8;  // 3B fp16 tokens/s: 4: 664, 6: 667, 8: 666, 12: 654, 16: 658, 24: 644
-    if (env_wpb >= 1 && env_wpb <= 8 && NU >= n_cu * 8) wpb = (uint32_t)env_wpb;
+    static const int env_wpb_mode[4] = {getenv("NFAI_GEMV_WPB_PLAIN") ? atoi(getenv("NFAI_GEMV_WPB_PLAIN")) : 0,
+                                        getenv("NFAI_GEMV_WPB_RES") ? atoi(getenv("NFAI_GEMV_WPB_RES")) : 0,
+                                        getenv("NFAI_GEMV_WPB_QKV") ? atoi(getenv("NFAI_GEMV_WPB_QKV")) : 0,
+                                        getenv("NFAI_GEMV_WPB_GATEUP") ? atoi(getenv("NFAI_GEMV_WPB_GATEUP")) : 0};
+    const int wpb_req = env_wpb ? env_wpb : env_wpb_mode[mode & 3];
+    if (wpb_req >= 1 && wpb_req <= 8 && NU >= n_cu * 8) wpb = (uint32_t)wpb_req;
     // workgroups per CU by epilogue mode (NFAI_GEMV_BPC_<MODE> overrides one mode, NFAI_GEMV_BPC all)
     static const int env_bpc_mode[4] = {getenv("NFAI_GEMV_BPC_PLAIN") ? atoi(getenv("NFAI_GEMV_BPC_PLAIN")) : 0,
                                         getenv("NFAI_GEMV_BPC_RES") ? atoi(getenv("NFAI_GEMV_BPC_RES")) : 0,

@@ -35,15 +35,33 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     vals[ctr] = {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
     subprocess.run(["rm", "-rf", d])  # the raw traces are tens of MB; gpurun copies back at most 64 MiB
 
-# algorithmic bytes per launch of the GEMV kernels at 3B: rows x K x bytes per weight
+# algorithmic bytes per launch of the GEMV kernels at 3B: rows x K x bytes per weight.  The kernel names carry the
+# launch geometry (k_gemv<WT, MODE, UPW, U, GUARD, NORM>), which tuning changes: match on weight type and epilogue mode instead.
 E, F, HD, KD = 3072, 8192, 3072, 1024
-ALG = {"nfai::k_gemv<1, 3, 2, 3, false, true>": 2 * F * E * 2, "nfai::k_gemv<1, 1, 3, 4, false, false>": E * F * 2,
-       "nfai::k_gemv<1, 2, 2, 3, false, true>": (HD + 2 * KD) * E * 2, "nfai::k_gemv<1, 1, 3, 3, false, false>": E * HD * 2,
-       "nfai::k_gemv_kqt<112, 3, 1, true, 0>": 2 * F * E * 144 // 256, "nfai::k_gemv_kqt<112, 1, 1, false, 1>": E * HD * 144 // 256,
-       "nfai::k_gemv_kqt<112, 1, 2, false, 2>": E * F * 144 // 256, "nfai::k_gemv_kqt<114, 1, 2, false, 2>": E * F * 210 // 256}
+V = 128256
+
+
+def algorithmic_bytes(name):
+    import re
+    m = re.match(r"nfai::k_gemv<(\d+), (\d+), (\d+), (\d+), (\w+), (\w+)>", name)
+    if m and m.group(1) == "1":
+        mode, u = int(m.group(2)), int(m.group(4))
+        if mode == 3:
+            return 2 * F * E * 2
+        if mode == 2:
+            return (HD + 2 * KD) * E * 2
+        if mode == 1:
+            return E * F * 2 if u == 4 else E * HD * 2   # Wdown streams K = 8192 (four 1-KiB loads per row and step), Wo K = 3072
+        if mode == 0 and m.group(6) == "true":
+            return V * E * 2
+    kq = {"nfai::k_gemv_kqt<112, 3, 1, true, 0>": 2 * F * E * 144 // 256, "nfai::k_gemv_kqt<112, 1, 1, false, 1>": E * HD * 144 // 256,
+          "nfai::k_gemv_kqt<112, 1, 2, false, 2>": E * F * 144 // 256, "nfai::k_gemv_kqt<114, 1, 2, false, 2>": E * F * 210 // 256}
+    return kq.get(name)
+
+
 out = {"command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --quant %s --steps 8 --warmup 2 "
                   "--no-cpu-baseline --profile-steps 0   (second pass with --pmc WRITE_SIZE; the benchmark's own context of 512 tokens); tools/pmc_traffic.py" % quant,
-       "engine": False, "dominant_kernel": "nfai::k_gemv<1, 3, 2, 3, false, true>" if quant == "f16" else "nfai::k_gemv_kqt<112, 3, 1, true, 0>",
+       "engine": False, "dominant_kernel": None,
        "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE reads exactly 1/2 of a 16 B/lane coalesced stream on gfx950 "
                      "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact",
        "model": "llama-3.2-3b " + ("fp16" if quant == "f16" else "Q4_K_M"), "kernels": {}}
@@ -52,9 +70,12 @@ for k, (fv, n) in vals["FETCH_SIZE"].items():
         continue
     wv = vals["WRITE_SIZE"].get(k, (0.0, 0))[0]
     e = {"FETCH_SIZE_KB_avg": fv, "launches": n, "WRITE_SIZE_KB_avg": wv, "hbm_bytes_per_launch": (2 * fv + wv) * 1024}
-    if k in ALG:
-        e["algorithmic_bytes_per_launch"] = ALG[k]
-        e["traffic_over_algorithmic"] = e["hbm_bytes_per_launch"] / ALG[k]
+    alg = algorithmic_bytes(k)
+    if alg:
+        e["algorithmic_bytes_per_launch"] = alg
+        e["traffic_over_algorithmic"] = e["hbm_bytes_per_launch"] / alg
+        if alg == (2 * F * E * 2 if quant == "f16" else 2 * F * E * 144 // 256):
+            out["dominant_kernel"] = k
     out["kernels"][k] = e
 json.dump(out, open(out_json, "w"), indent=1)
 for k, e in out["kernels"].items():
