@@ -358,11 +358,14 @@ __device__ __forceinline__ float silu_ref(float x)
 }
 
 // Block-wide sum (<= 16 waves); every thread gets the total.  `red` is >= 16 floats of LDS.
+// FRESH: `red` has not been read or written in this launch yet, so nothing has to be kept apart from the write below (the GEMV
+// prologues: one barrier fewer on the way to the first FMA).
+template <bool FRESH = false>
 __device__ __forceinline__ float block_sum(float v, float *red)
 {
     v = wave_sum(v);
     const int wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    __syncthreads();
+    if constexpr (!FRESH) __syncthreads();
     if ((threadIdx.x & 63) == 0) red[wid] = v;
     __syncthreads();
     // fixed trip count (<= 16 waves): the LDS reads issue back to back; with the runtime bound hipcc emits a serial

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
                 ss = fmaf(xv[i][2], xv[i][2], ss);
                 ss = fmaf(xv[i][3], xv[i][3], ss);
             }
-            ss = block_sum(ss, red);
+            ss = block_sum<true>(ss, red);
             rms = sqrtf(ss / (float)p.K + p.eps);
         }
 #pragma unroll
