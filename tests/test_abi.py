@@ -177,6 +177,10 @@ def test_csharp_sources_call_declared_entry_points_and_have_no_stubs():
 
 def _build_c_driver(tmp_path):
     import subprocess
+    from nfai_amd import build as hb
+    import oracle  # noqa: F401  (compiles oracle/libnfai_oracle.so on first import)
+    hb.build()
+    assert os.path.exists(os.path.join(ROOT, "oracle", "libnfai_oracle.so"))
     exe = str(tmp_path / "run_llama")
     r = subprocess.run(["gcc", "-O2", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
                         os.path.join(ROOT, "tests", "c_driver", "run_llama.c"), "-o", exe,
