@@ -1208,19 +1208,22 @@ hipError_t launch_softmax_causal_rows(const float *sc, void *p_f16, uint32_t H, 
 #define ATTN_PF_NST 3  // stages of the K / V^T ring (measured per launch at 3B, T = 512: 3 stages 22.2 us, 6 stages 22.6 us — the step is
                        // bound by its dependent chain S-MFMAs -> max -> exp -> P.V-MFMAs with one wave per SIMD, not by the tiles' latency)
 #endif
-template <int D>
-__global__ __launch_bounds__(256) void k_attn_prefill(const _Float16 *QH, const _Float16 *KH, const _Float16 *VT, _Float16 *O, uint32_t T,
+// KG = 2: two wave groups per 16-row tile split every 64 keys of a step between them (each its own 32-key sub-tile of K and V^T) and
+// merge their (max, sum, output) through LDS at the end: the dependent chain of a step is walked half as often per wave.
+template <int D, int KG>
+__global__ __launch_bounds__(256 * KG) void k_attn_prefill(const _Float16 *QH, const _Float16 *KH, const _Float16 *VT, _Float16 *O, uint32_t T,
                                                       uint32_t H, uint32_t G, uint32_t Spad, uint32_t pos0, float scale)
 {
     constexpr int KK = D / 32, DT = D / 16, NST = ATTN_PF_NST;
     constexpr int KROW = D * 2;                  // bytes of a key row in the K tile (D / 8 chunks of 16 B)
     constexpr int KCH = D / 8;                   // chunks per key row
-    constexpr int K_BYTES = 32 * KROW, V_BYTES = D * 64, STAGE = K_BYTES + V_BYTES;
+    constexpr int K_BYTES = 32 * KROW, V_BYTES = D * 64, SUB = K_BYTES + V_BYTES, STAGE = SUB * KG;
     constexpr int KI = K_BYTES / 1024, VI = V_BYTES / 1024;  // LDS-DMA instructions per tile (1 KiB each)
     static_assert(KI % 4 == 0 && VI % 4 == 0, "instructions divide over the four waves");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     typedef __attribute__((address_space(3))) uint8_t lds_u8;
-    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63, wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wave = wave_all & 3, kg = wave_all >> 2;  // query tile of the workgroup, key group
     const uint32_t qi = lane & 15, g = lane >> 4;
     const uint32_t qblocks = (T + 63) / 64;
     const uint32_t qb = qblocks - 1 - blockIdx.x;  // long rows first
@@ -1234,7 +1237,7 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const _Float16 *QH, const 
     const GLOBAL_AS uint8_t *Kb = (const GLOBAL_AS uint8_t *)(KH + (uint64_t)kvh * Spad * D);
     const GLOBAL_AS uint8_t *Vb = (const GLOBAL_AS uint8_t *)(VT + (uint64_t)kvh * D * Spad);
     const uint32_t kmax = pos0 + min(qb * 64 + 63, T - 1) + 1;  // keys the workgroup's last row can see (exclusive)
-    const uint32_t nsteps = (kmax + 31) / 32;                   // block-uniform
+    const uint32_t nsteps = (kmax + 32 * KG - 1) / (32 * KG);   // block-uniform; a step covers 32 keys per key group
     const uint32_t my_last = pos0 + q0 + qi;                    // last key of this lane's query
 
     // per-lane source offsets of this wave's LDS-DMA instructions (K: 4 keys per instruction, V^T: 16 d rows per instruction)
@@ -1251,13 +1254,13 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const _Float16 *QH, const 
         vsrc[i] = dd * Spad * 2 + ((c ^ ((dd >> 2) & 3)) * 16);
     }
     auto issue = [&](uint32_t st, uint32_t stage) {
-        const uint32_t k0 = min(st, nsteps - 1) * 32;
+        const uint32_t k0 = (min(st, nsteps - 1) * KG + kg) * 32;  // this key group's sub-tile
 #pragma unroll
         for (int i = 0; i < KI / 4; i++)
-            __builtin_amdgcn_global_load_lds(Kb + (uint64_t)k0 * KROW + ksrc[i], (lds_u8 *)(lds + stage * STAGE + (i * 4 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(Kb + (uint64_t)k0 * KROW + ksrc[i], (lds_u8 *)(lds + stage * STAGE + kg * SUB + (i * 4 + wave) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < VI / 4; i++)
-            __builtin_amdgcn_global_load_lds(Vb + (uint64_t)k0 * 2 + vsrc[i], (lds_u8 *)(lds + stage * STAGE + K_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(Vb + (uint64_t)k0 * 2 + vsrc[i], (lds_u8 *)(lds + stage * STAGE + kg * SUB + K_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
     };
     f32x4 acc[DT];
 #pragma unroll
@@ -1271,8 +1274,8 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const _Float16 *QH, const 
         wait_vmcnt<(KI / 4 + VI / 4) * (NST - 2)>();
         __builtin_amdgcn_s_barrier();
         issue(st + NST - 1, fill);
-        const uint8_t *lk = lds + cur * STAGE, *lv = lk + K_BYTES;
-        const uint32_t k0 = st * 32;
+        const uint8_t *lk = lds + cur * STAGE + kg * SUB, *lv = lk + K_BYTES;
+        const uint32_t k0 = (st * KG + kg) * 32;
         f32x4 sc[2];
 #pragma unroll
         for (int kt = 0; kt < 2; kt++) {
@@ -1325,6 +1328,29 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const _Float16 *QH, const 
         fill = fill + 1 == NST ? 0 : fill + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus DMAs of the last iterations must not outlive the workgroup's LDS
+    if constexpr (KG == 2) {
+        // merge the two key groups of a query tile through LDS (the ring is free now): group 1 hands (max, partial sum, output) over
+        __syncthreads();
+        float *mb = reinterpret_cast<float *>(lds) + (size_t)(wave * 64 + lane) * (2 + DT * 4);
+        if (kg == 1) {
+            mb[0] = m;
+            mb[1] = l;
+#pragma unroll
+            for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) mb[2 + dt * 4 + r] = acc[dt][r];
+        }
+        __syncthreads();
+        if (kg == 1) return;
+        const float m1 = mb[0], l1 = mb[1];
+        const float M = fmaxf(m, m1);
+        const float a0 = __expf(fmaxf(m - M, -80.f)), a1 = __expf(fmaxf(m1 - M, -80.f));
+        l = l * a0 + l1 * a1;
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[dt][r] = acc[dt][r] * a0 + mb[2 + dt * 4 + r] * a1;
+    }
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
     const float inv = 1.0f / l;
@@ -1346,19 +1372,26 @@ hipError_t launch_attn_prefill(const void *qh, const void *kh, const void *vt, v
     if (Hkv == 0 || H % Hkv || Spad % 32 || pos0 + T > Spad || (D != 64 && D != 128)) return hipErrorInvalidValue;
     const dim3 grid((T + 63) / 64, H);
     const float scale = 1.0f / sqrtf((float)D);  // AttentionScoreCalculationShader.cs:93
-    const size_t lds = (size_t)ATTN_PF_NST * (32 * D * 2 + D * 64);
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn_prefill<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    if (D == 128)
-        k_attn_prefill<128><<<grid, 256, lds, s>>>(static_cast<const _Float16 *>(qh), static_cast<const _Float16 *>(kh),
-                                                   static_cast<const _Float16 *>(vt), static_cast<_Float16 *>(out_f16), T, H, H / Hkv, Spad, pos0, scale);
-    else
-        k_attn_prefill<64><<<grid, 256, lds, s>>>(static_cast<const _Float16 *>(qh), static_cast<const _Float16 *>(kh),
-                                                  static_cast<const _Float16 *>(vt), static_cast<_Float16 *>(out_f16), T, H, H / Hkv, Spad, pos0, scale);
+    // two key groups per query tile (512 threads) unless NFAI_PREFILL_ATTN_KG=1
+    static const int env_kg = getenv("NFAI_PREFILL_ATTN_KG") ? atoi(getenv("NFAI_PREFILL_ATTN_KG")) : 2;
+    const int kg = (env_kg == 1 || Spad % 64) ? 1 : 2;  // a step of two key groups covers 64 keys
+    const size_t lds = (size_t)ATTN_PF_NST * (32 * D * 2 + D * 64) * kg;
+    const _Float16 *q = static_cast<const _Float16 *>(qh), *k = static_cast<const _Float16 *>(kh), *v = static_cast<const _Float16 *>(vt);
+    _Float16 *o = static_cast<_Float16 *>(out_f16);
+    const uint32_t G = H / Hkv;
+#define NFAI_APF(D_, KG_)                                                                                                                  \
+    do {                                                                                                                                   \
+        static bool attr_set = false;                                                                                                      \
+        if (lds > 64 * 1024 && !attr_set) {                                                                                                \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_attn_prefill<D_, KG_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                                                                 \
+            attr_set = true;                                                                                                               \
+        }                                                                                                                                  \
+        k_attn_prefill<D_, KG_><<<grid, 256 * KG_, lds, s>>>(q, k, v, o, T, H, G, Spad, pos0, scale);                                       \
+    } while (0)
+    if (D == 128) { if (kg == 2) NFAI_APF(128, 2); else NFAI_APF(128, 1); }
+    else { if (kg == 2) NFAI_APF(64, 2); else NFAI_APF(64, 1); }
+#undef NFAI_APF
     return hipGetLastError();
 }
 
