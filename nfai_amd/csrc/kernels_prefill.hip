@@ -1051,11 +1051,89 @@ __global__ void k_rope_store_rows(const float *q, const float *k, const float *v
     }
 }
 
+// The same work in tiles of 32 positions x one head (workgroup = 256 threads): rows are read and written 8 bytes per thread along d
+// (coalesced), and the fp16 V^T of the chunk — rows along the positions — goes through LDS so that it is written 32 bytes per
+// thread along the positions instead of two bytes at a stride of Spad (the scattered stores were what the per-pair kernel above
+// spent its 9.5 us per block on at 3B, T = 512; it stays for head sizes above 128 and as the reference form).
+__global__ __launch_bounds__(256) void k_rope_store_tiles(const float *q, const float *k, const float *v, _Float16 *qh, void *kc, void *vc,
+                                                          int kv_f16, uint64_t pos_stride, uint64_t head_stride, const float *freqs,
+                                                          uint32_t rope_dims, uint32_t H, uint32_t Hkv, uint32_t D, uint32_t pos0, uint32_t T,
+                                                          uint32_t ld, _Float16 *kh, _Float16 *vt, uint32_t Spad)
+{
+    __shared__ _Float16 vtile[128][32 + 8];  // [d][position of the tile], padded rows
+    const uint32_t half = D / 2, rpp = 256 / half;  // rows per pass
+    const uint32_t hh = blockIdx.y, t0 = blockIdx.x * 32, tid = threadIdx.x;
+    const uint32_t which = hh < H ? 0u : (hh < H + Hkv ? 1u : 2u);
+    const uint32_t h = which == 0 ? hh : (which == 1 ? hh - H : hh - H - Hkv);
+    const float *src0 = which == 0 ? q : (which == 1 ? k : v);
+    const uint32_t pr = tid % half, rr = tid / half, pair = pr * 2;
+    const bool rot = which < 2 && pair < rope_dims;
+    const float fr = rot ? freqs[pr] : 0.f;
+    for (uint32_t r0 = 0; r0 < 32; r0 += rpp) {
+        const uint32_t tl = r0 + rr, t = t0 + tl;
+        if (rr < rpp && t < T) {
+            const uint32_t pos = pos0 + t;
+            const f32x2 ab = *reinterpret_cast<const f32x2 *>(src0 + (uint64_t)t * ld + h * D + pair);
+            float o0 = ab[0], o1 = ab[1];
+            if (rot) {  // RoPEShader.cs:249-262 (a per-chunk cos / sin table instead of cosf / sinf here was measured: no change)
+                const float theta = fr * (float)pos;
+                const float c = cosf(theta), sn = sinf(theta);
+                o0 = c * ab[0] - sn * ab[1];
+                o1 = sn * ab[0] + c * ab[1];
+            }
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const h2 oh = {(_Float16)o0, (_Float16)o1};
+            if (which == 0) {
+                *reinterpret_cast<h2 *>(qh + (uint64_t)t * H * D + h * D + pair) = oh;
+            } else {
+                void *base = which == 1 ? kc : vc;
+                const uint64_t o = (uint64_t)pos * pos_stride + (uint64_t)h * head_stride + pair;
+                if (kv_f16) *reinterpret_cast<h2 *>(reinterpret_cast<_Float16 *>(base) + o) = oh;
+                else *reinterpret_cast<f32x2 *>(reinterpret_cast<float *>(base) + o) = f32x2{o0, o1};
+                if (kh) {
+                    if (which == 1) {
+                        *reinterpret_cast<h2 *>(kh + ((uint64_t)h * Spad + pos) * D + pair) = oh;
+                    } else {
+                        vtile[pair][tl] = oh[0];
+                        vtile[pair + 1][tl] = oh[1];
+                    }
+                }
+            }
+        }
+    }
+    if (which == 2 && kh) {
+        __syncthreads();
+        // V^T rows of the tile: thread = (d, half of the 32 positions); 16 positions = 32 bytes when the destination is 16-byte
+        // aligned and the tile is full, else element by element
+        const uint32_t d = tid / 2, hp = tid % 2;
+        if (d < D) {
+            _Float16 *dst = vt + ((uint64_t)h * D + d) * Spad + pos0 + t0 + hp * 16;
+            const uint32_t nvalid = t0 + hp * 16 < T ? min(16u, T - (t0 + hp * 16)) : 0u;
+            if (nvalid == 16 && ((pos0 + t0) % 8) == 0) {
+                const u32x4 a = *reinterpret_cast<const u32x4 *>(&vtile[d][hp * 16]);
+                const u32x4 b = *reinterpret_cast<const u32x4 *>(&vtile[d][hp * 16 + 8]);
+                *reinterpret_cast<u32x4 *>(dst) = a;
+                *reinterpret_cast<u32x4 *>(dst + 8) = b;
+            } else {
+                for (uint32_t i = 0; i < nvalid; i++) dst[i] = vtile[d][hp * 16 + i];
+            }
+        }
+    }
+}
+
 hipError_t launch_rope_store_rows(const float *q, const float *k, const float *v, void *qh, void *kc, void *vc, int kv_f16,
                                   uint64_t pos_stride, uint64_t head_stride, const float *freqs, uint32_t rope_dims, uint32_t H,
                                   uint32_t Hkv, uint32_t D, uint32_t pos0, uint32_t T, uint32_t ld, void *kh, void *vt, uint32_t Spad,
                                   hipStream_t s)
 {
+    static const int env_tiles = getenv("NFAI_PREFILL_ROPE_TILES") ? atoi(getenv("NFAI_PREFILL_ROPE_TILES")) : 1;
+    // tiles: D/2 pairs must divide the 256 threads of a workgroup, rows 8-byte aligned
+    if (env_tiles && D <= 128 && D >= 8 && 256 % (D / 2) == 0 && D % 2 == 0 && ld % 2 == 0 && (pos_stride % 2) == 0 && (head_stride % 2) == 0) {
+        k_rope_store_tiles<<<dim3((T + 31) / 32, H + 2 * Hkv), 256, 0, s>>>(q, k, v, static_cast<_Float16 *>(qh), kc, vc, kv_f16, pos_stride,
+                                                                          head_stride, freqs, rope_dims, H, Hkv, D, pos0, T, ld,
+                                                                          static_cast<_Float16 *>(kh), static_cast<_Float16 *>(vt), Spad);
+        return hipGetLastError();
+    }
     const uint32_t n = (H + 2 * Hkv) * D / 2;
     k_rope_store_rows<<<dim3((n + 255) / 256, T), 256, 0, s>>>(q, k, v, static_cast<_Float16 *>(qh), kc, vc, kv_f16, pos_stride,
                                                                head_stride, freqs, rope_dims, H, Hkv, D, pos0, ld,
