@@ -126,3 +126,95 @@ def test_pipeline_schedule_gloo(world):
             tok = orc.argmax(ref.step(tok))
             want.append(tok)
         assert got[s] == want, (s, got[s], want)
+
+
+# ---- properties of the host logic (hypothesis): any world size, any model depth ------------------------------------------------
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+
+@settings(max_examples=200, deadline=None)
+@given(n_layers=st.integers(1, 80), world=st.integers(1, 8), layer_cost=st.floats(0.5, 500.0), head_ratio=st.floats(0.0, 12.0))
+def test_partition_layers_properties(n_layers, world, layer_cost, head_ratio):
+    """Contiguous, covering, every stage >= 1 block, and minimax: no other contiguous partition has a smaller largest stage
+    (checked against the exact optimum, which for contiguous equal-cost blocks is a one-dimensional search over the last
+    stage's size)."""
+    if world > n_layers:
+        world = n_layers
+    head = head_ratio * layer_cost
+    r = partition_layers(n_layers, world, layer_cost, head)
+    assert len(r) == world and r[0][0] == 0 and r[-1][1] == n_layers
+    assert all(a[1] == b[0] for a, b in zip(r, r[1:])) and all(e > b for b, e in r)
+    cost = max((e - b) * layer_cost + (head if i == world - 1 else 0.0) for i, (b, e) in enumerate(r))
+    if world == 1:
+        best = n_layers * layer_cost + head
+    else:
+        best = min(max(k * layer_cost + head, -(-(n_layers - k) // (world - 1)) * layer_cost)
+                   for k in range(1, n_layers - (world - 1) + 1))
+    assert cost <= best * (1 + 1e-9) + 1e-9, (r, cost, best)
+
+
+class _TraceStage:
+    """Records what the schedule asks of a stage; buffers are (kind, slot) tokens so that sends and receives can be matched."""
+
+    def __init__(self):
+        self.calls = []
+
+    def h_in(self, s):
+        return ("h_in", s)
+
+    def h_out(self, s):
+        return ("h_out", s)
+
+    def tok(self, s):
+        return ("tok", s)
+
+    def first(self, slot, token):
+        self.calls.append(("first", slot, token))
+
+    def middle(self, slot):
+        self.calls.append(("middle", slot))
+
+    def last(self, slot):
+        self.calls.append(("last", slot))
+
+    def last_from_first(self, slot):
+        self.calls.append(("last_from_first", slot))
+
+
+@settings(max_examples=60, deadline=None)
+@given(world=st.integers(1, 8), n_steps=st.integers(1, 9))
+def test_schedule_ticks_properties(world, n_steps):
+    """For every world size and step count: in every tick each posted send has exactly one matching receive on its peer in the
+    SAME tick (no deadlock under rendezvous semantics), every stage runs every (slot, step) job exactly once and in step order
+    per slot, the first stage gets a host token only at step 0, and a hidden state is always consumed in the tick after it was
+    produced."""
+    from nfai_amd.pipeline import schedule_ticks
+    stages = [_TraceStage() for _ in range(world)]
+    firsts = [100 + s for s in range(world)]
+    gens = [schedule_ticks(stages[r], r, world, n_steps, firsts) for r in range(world)]
+    n_ticks = 0
+    for posted in zip(*gens):
+        n_ticks += 1
+        for r, (sends, recvs) in enumerate(posted):
+            for buf, dst in sends:
+                match = [b for b, src in posted[dst][1] if src == r]
+                assert len(match) == 1, (world, n_steps, r, dst)
+                # a hidden state goes into the same slot's input; a token into the same slot's token word
+                assert match[0][1] == buf[1] and {buf[0], match[0][0]} in ({"h_out", "h_in"}, {"tok"})
+            for buf, src in recvs:
+                assert sum(1 for b, dst in posted[src][0] if dst == r) >= 1
+        assert sum(len(s_) for s_, _ in posted) == sum(len(r_) for _, r_ in posted)
+    assert n_ticks == n_steps * world + world - 1
+    for r, stg in enumerate(stages):
+        kind = "first" if r == 0 else ("last" if r == world - 1 else "middle")
+        jobs = [c for c in stg.calls if c[0] == kind]
+        assert len(jobs) == n_steps * world
+        per_slot = {}
+        for c in jobs:
+            per_slot.setdefault(c[1], []).append(c)
+        assert sorted(per_slot) == list(range(world)) and all(len(v) == n_steps for v in per_slot.values())
+        if r == 0:
+            for slot, v in per_slot.items():
+                assert v[0][2] == firsts[slot] and all(c[2] is None for c in v[1:])
+    if world == 1:
+        assert sum(1 for c in stages[0].calls if c[0] == "last_from_first") == n_steps
