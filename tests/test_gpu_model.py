@@ -467,3 +467,26 @@ def test_engine_pipeline_stages_and_fallback(mgr):
     np.testing.assert_array_equal(a.Step(3)[0], b.Step(3)[0])
     a.Dispose()
     b.Dispose()
+
+
+def test_full_size_parity_through_bench():
+    """The whole Llama-3.2-3B (BASELINE config 3: 28 blocks, vocabulary 128256, 6.4 GB of fp16 weights) at full size: `bench.py`
+    runs the oracle on the same weights (its `cpu_baseline` leg, here 4 tokens) and compares the first token's full logit vector
+    with the GPU's, and compares the 512-token MFMA prefill with the token-by-token decode path.  The tolerances are the
+    end-to-end ones of this file; the line must also carry the contract's roofline fields."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "16", "--warmup", "2", "--cpu-tokens", "4"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["max_abs_logit_diff_vs_gpu_token0"] <= 2e-3   # logits are O(1) here
+    chk = d["prefill"]["check"]
+    assert chk["same_argmax"] and chk["max_abs_logit_diff"] <= chk["tolerance"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and 0.3 < rf["frac"] < 1.0 and rf["traffic"] and 0.95 < rf["traffic"] / rf["bytes_per_launch"] < 1.1
+    assert d["n_gpus"] == 1 and d["steps"] == 16 and d["value"] > 100
