@@ -469,18 +469,20 @@ def test_engine_pipeline_stages_and_fallback(mgr):
     b.Dispose()
 
 
-def test_full_size_parity_through_bench():
+@pytest.mark.parametrize("quant", ["f16", "q4_k_m"])
+def test_full_size_parity_through_bench(quant):
     """The whole Llama-3.2-3B (BASELINE config 3: 28 blocks, vocabulary 128256, 6.4 GB of fp16 weights) at full size: `bench.py`
     runs the oracle on the same weights (its `cpu_baseline` leg, here 4 tokens) and compares the first token's full logit vector
     with the GPU's, and compares the 512-token MFMA prefill with the token-by-token decode path.  The tolerances are the
-    end-to-end ones of this file; the line must also carry the contract's roofline fields."""
+    end-to-end ones of this file; the line must also carry the contract's roofline fields.  Also as Q4_K_M (BASELINE config 4:
+    Q4_K / Q6_K blocks; the oracle multiplies the dequantised weights)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "16", "--warmup", "2", "--cpu-tokens", "4"],
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "16", "--warmup", "2", "--cpu-tokens", "4", "--quant", quant],
                        env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
