@@ -492,3 +492,25 @@ def test_full_size_parity_through_bench(quant):
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and 0.3 < rf["frac"] < 1.0 and rf["traffic"] and 0.95 < rf["traffic"] / rf["bytes_per_launch"] < 1.1
     assert d["n_gpus"] == 1 and d["steps"] == 16 and d["value"] > 100
+
+
+@pytest.mark.parametrize("dims", [synth.LLAMA_32_3B, synth.LLAMA_32_1B], ids=lambda d: d.name)
+def test_decode_is_bit_reproducible(mgr, dims):
+    """The hand-offs inside the launches (attention slices, attention -> Wo) are ordered by data, not by arrival: the same 150
+    tokens twice (after a reset) and on a second model instance must give bit-identical logits at every step — slice merges
+    run in fixed slice order whatever block publishes first."""
+    from dataclasses import replace
+    from nfai_amd.llama_model import LlamaModel
+    d2 = replace(dims, L=2, V=2048, name=dims.name + "-2blk")
+    w = synth.make_weights(d2, seed=41)
+    toks = synth.make_tokens(d2, 150, seed=17)
+    m = LlamaModel(mgr, synth.make_metadata(d2), w, 160)
+    first = [m.Step(int(t))[0].copy() for t in toks]
+    m.Reset()
+    for i, t in enumerate(toks):
+        assert np.array_equal(m.Step(int(t))[0], first[i]), i
+    m2 = LlamaModel(mgr, synth.make_metadata(d2), w, 160, graph=False)
+    for i, t in enumerate(toks):
+        assert np.array_equal(m2.Step(int(t))[0], first[i]), i
+    m.Dispose()
+    m2.Dispose()
