@@ -46,7 +46,6 @@ public sealed unsafe class HipLlamaModel : IInferenceProvider
 {
     private readonly ulong model;
     private readonly Tokenizer tokenizer;
-    private readonly float[] logits;
     private bool firstInput = true;
 
     public string ModelName { get; init; }
@@ -95,7 +94,6 @@ public sealed unsafe class HipLlamaModel : IInferenceProvider
             Native.nfai_hip_llama_destroy(model);
             throw;
         }
-        logits = new float[desc.V];
     }
 
     public async IAsyncEnumerable<ChatResponseUpdate> GetStreamingResponseAsync(IEnumerable<ChatMessage> messages, ChatOptions? options = null,
@@ -121,33 +119,60 @@ public sealed unsafe class HipLlamaModel : IInferenceProvider
     {
         var tokenIds = tokenizer.Tokenize(prompt, addBos: firstInput);                          // :101
         firstInput = false;
-        uint argmax = 0;
-        foreach (var token in tokenIds) argmax = Step(token);                                   // :103-126
-        var tk = Greedy ? argmax : SamplingUtils.TopP(logits);                                  // :128-130
+        for (int i = 0; i + 1 < tokenIds.Count; i++) Step(tokenIds[i], sample: false);          // :103-126 (only the last output is sampled)
+        var tk = Step(tokenIds[^1], sample: true);                                              // :128-130
         yield return tokenizer.Detokenize([tk]);
         while (tk != tokenizer.EosTokenId && !ct.IsCancellationRequested)                       // :134-173
         {
-            argmax = Step(tk);
-            tk = Greedy ? argmax : SamplingUtils.TopP(logits);
+            tk = Step(tk, sample: true);
             if (tk != tokenizer.EosTokenId) yield return tokenizer.Detokenize([tk]);
         }
         await Task.CompletedTask;
     }
 
-    /// <summary>One token through embed → blocks → norm → lm_head (one graph replay); returns the device-side argmax and fills
-    /// `logits` (skipped in greedy mode: 513 KB less per token over PCIe).</summary>
-    private uint Step(uint token)
+    private readonly uint[] candidateIds = new uint[TopK];
+    private readonly float[] candidateProbs = new float[TopK];
+    private const int TopK = 40;                                                                // SamplingUtils.cs:5 defaults
+    private const float Temperature = 0.5f, TopPValue = 0.95f;
+
+    /// <summary>One token through embed → blocks → norm → lm_head (one graph replay) and the next token: ArgMax on the device in
+    /// greedy mode; otherwise the reference's default sampler (SamplingUtils.TopP) with its first half — values / temperature,
+    /// softmax over V, stable descending order, Take(40), SamplingUtils.cs:7-13 — on the device: 328 bytes cross PCIe instead of
+    /// the 513 KB of logits the reference reads back (LlamaModel.cs:128,165).</summary>
+    private uint Step(uint token, bool sample)
     {
         uint argmax;
-        if (Greedy)
+        if (Greedy || !sample)
         {
             Native.Check(Native.nfai_hip_llama_decode_step(model, token, null, &argmax));
+            return argmax;
         }
-        else
+        fixed (uint* ids = candidateIds)
+        fixed (float* probs = candidateProbs)
+            Native.Check(Native.nfai_hip_llama_decode_topk(model, token, Temperature, TopK, ids, probs));
+        return TopPFromCandidates(candidateIds, candidateProbs, TopPValue, Random.Shared.NextSingle());
+    }
+
+    /// <summary>SamplingUtils.cs:14-31 on the candidates Take(topK) leaves: nucleus cut (the element that crosses topP is kept),
+    /// renormalise, draw.  Same statements as the reference, so that a given `rand` selects the same token.</summary>
+    internal static uint TopPFromCandidates(uint[] ids, float[] probs, float topP, float rand)
+    {
+        float cumulative = 0f;
+        List<(uint idx, float prob)> topPList = [];
+        for (int i = 0; i < ids.Length; i++)
         {
-            fixed (float* p = logits) Native.Check(Native.nfai_hip_llama_decode_step(model, token, p, &argmax));
+            cumulative += probs[i];
+            topPList.Add((ids[i], probs[i]));
+            if (cumulative >= topP) break;
         }
-        return argmax;
+        float total = topPList.Sum(x => x.prob);
+        float running = 0f;
+        foreach (var (idx, prob) in topPList)
+        {
+            running += prob / total;
+            if (rand < running) return idx;
+        }
+        return topPList[^1].idx;
     }
 
     /// <summary>New conversation: position 0 (the reference never resets currentToken, TransformerBlock.cs:183).</summary>

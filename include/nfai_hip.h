@@ -138,6 +138,11 @@ int32_t nfai_hip_add(nfai_ctx_t ctx, nfai_buf_t a, nfai_buf_t b, nfai_buf_t y, u
 /* SamplingUtils.ArgMax (NFAI.Models.Llama3/SamplingUtils.cs:43-57): index of the first maximum,
  * written as one uint32 to `out_idx`. */
 int32_t nfai_hip_argmax(nfai_ctx_t ctx, nfai_buf_t x, uint32_t n, nfai_buf_t out_idx);
+/* The device half of SamplingUtils.TopP (NFAI.Models.Llama3/SamplingUtils.cs:5-13): values / temperature (:7), Softmax over all n
+ * (:8, :35-41), OrderByDescending(Prob) (stable: equal probabilities in index order, :9-12), Take(k) (:13) -> ids_out[k],
+ * probs_out[k] (host arrays; k <= 64, the reference's topK is 40).  One launch over the logits and 8k + 8 bytes back instead of n
+ * floats; the nucleus cut and the Random.Shared draw (:14-31) stay with the caller.  Blocking. */
+int32_t nfai_hip_topk(nfai_ctx_t ctx, nfai_buf_t x, uint32_t n, float temperature, uint32_t k, uint32_t *ids_out, float *probs_out);
 
 /* ---- fused operators (no reference counterpart: each replaces the chain named) ---- */
 /* scores -> softmax -> weighted sum in one KV-cache pass, GQA heads sharing each K/V read.
@@ -241,6 +246,11 @@ int32_t nfai_hip_llama_share_tensors(nfai_model_t model, nfai_model_t donor);
 /* One token through embed -> blocks -> output_norm -> lm_head (LlamaModel.cs:116-125) at the
  * current position; logits_host (V floats) and argmax may be NULL.  Blocking. */
 int32_t nfai_hip_llama_decode_step(nfai_model_t model, uint32_t token, float *logits_host, uint32_t *argmax);
+/* One token as _decode_step, then the candidates of the reference's DEFAULT sampler (LlamaModel.cs:128-130,165 call
+ * SamplingUtils.TopP on V logits read back to the host): the k most probable tokens under softmax(logits / temperature) and their
+ * probabilities, as nfai_hip_topk.  The caller finishes TopP (SamplingUtils.cs:14-31: nucleus 0.95, renormalise, draw).  Blocking;
+ * less than 1 KB crosses PCIe per token. */
+int32_t nfai_hip_llama_decode_topk(nfai_model_t model, uint32_t token, float temperature, uint32_t k, uint32_t *ids_out, float *probs_out);
 /* Greedy loop with the token fed back on the device (ArgMax in place of the stochastic TopP,
  * SamplingUtils.cs:5-33 vs :43-57): n_steps tokens starting from `first_token`; tokens_out[i] is
  * the argmax after step i.  One hipGraph replay per token, no host round trip. */

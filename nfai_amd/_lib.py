@@ -76,6 +76,7 @@ SIGNATURES = {
     "nfai_hip_mul": [H, H, H, H, u32],
     "nfai_hip_add": [H, H, H, H, u32],
     "nfai_hip_argmax": [H, H, u32, H],
+    "nfai_hip_topk": [H, H, u32, f32, u32, C.POINTER(u32), C.POINTER(f32)],
     "nfai_hip_attn_decode": [H, H, H, H, H, u32, u32, u32, u32, u32, i32],
     "nfai_hip_gemv_fused": [H, H, i32, H, H, f32, H, H, u32, u32],
     "nfai_hip_gemv_gateup_silu": [H, H, H, i32, H, H, f32, H, u32, u32],
@@ -88,6 +89,7 @@ SIGNATURES = {
     "nfai_hip_llama_finalize": [H],
     "nfai_hip_llama_share_tensors": [H, H],
     "nfai_hip_llama_decode_step": [H, u32, C.POINTER(f32), C.POINTER(u32)],
+    "nfai_hip_llama_decode_topk": [H, u32, f32, u32, C.POINTER(u32), C.POINTER(f32)],
     "nfai_hip_llama_decode_greedy": [H, u32, u32, C.POINTER(u32)],
     "nfai_hip_llama_decode_enqueue": [H, u32],
     "nfai_hip_llama_set_token": [H, u32],
@@ -132,7 +134,10 @@ def load() -> C.CDLL:
         L.nfai_hip_last_error.argtypes = []
         L.nfai_hip_abi_version.restype = i32
         L.nfai_hip_abi_version.argtypes = []
+        lax = bool(os.environ.get("NFAI_HIP_LIB_LAX"))  # A/B runs against a library built from an older revision (tools/build_ref.sh)
         for name, args in SIGNATURES.items():
+            if lax and not hasattr(L, name):
+                continue
             fn = getattr(L, name)  # AttributeError here = header/library mismatch
             fn.restype = i32
             fn.argtypes = args

@@ -548,6 +548,52 @@ NFAI_API int32_t nfai_hip_argmax(nfai_ctx_t h, nfai_buf_t x, uint32_t n, nfai_bu
     return NFAI_OK;
 }
 
+// ---- candidates of SamplingUtils.TopP (SamplingUtils.cs:5-33) -------------------------------------------------------------------
+namespace nfai {
+// Host half: what the device left (k largest logits, descending, ties by index; M = max(l / T); S = sum exp(l / T - M)) -> the
+// (index, probability) pairs OrderByDescending(Prob).Take(k) yields (:9-13): p = exp(l / T - M) / S (:7, :38-40), ordered by
+// probability descending, equal probabilities by index (the reference's sort is stable over the index order).
+void topk_finish(const float *vals, const uint32_t *ids, float M, float S, float temperature, uint32_t k, uint32_t *ids_out, float *probs_out)
+{
+    for (uint32_t j = 0; j < k; j++) {
+        const float p = expf(vals[j] / temperature - M) / S;
+        uint32_t at = j;  // insertion: exp is monotonic, so only runs of EQUAL probabilities (different logits) can need reordering
+        while (at > 0 && probs_out[at - 1] == p && ids_out[at - 1] > ids[j]) {
+            probs_out[at] = probs_out[at - 1];
+            ids_out[at] = ids_out[at - 1];
+            at--;
+        }
+        probs_out[at] = p;
+        ids_out[at] = ids[j];
+    }
+}
+
+int topk_run(Ctx *c, const float *logits_dev, uint32_t n, float temperature, uint32_t k, void *work, uint32_t *ids_out, float *probs_out)
+{
+    if (!ids_out || !probs_out) return fail(NFAI_ERR_INVALID, "topk: null output");
+    if (k == 0 || k > TOPK_MAX || k > n) return fail(NFAI_ERR_INVALID, "topk: k=%u outside [1, min(%u, n=%u)]", k, TOPK_MAX, n);
+    if (!(temperature > 0.f)) return fail(NFAI_ERR_INVALID, "topk: temperature %g (the reference divides by it, SamplingUtils.cs:7)", temperature);
+    hipError_t e = launch_topk(logits_dev, n, temperature, k, work, c->stream);
+    if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? NFAI_ERR_INVALID : NFAI_ERR_HIP, "topk launch failed: %s", hipGetErrorString(e));
+    struct { float v[TOPK_MAX]; uint32_t i[TOPK_MAX]; float M, S; } out;  // the head of the workspace behind its ticket words (320 + 8 bytes used at k = 40)
+    HIP_TRY(hipMemcpyAsync(&out, static_cast<const char *>(work) + topk_out_offset(), sizeof(out), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    topk_finish(out.v, out.i, out.M, out.S, temperature, k, ids_out, probs_out);
+    return NFAI_OK;
+}
+}  // namespace nfai
+
+NFAI_API int32_t nfai_hip_topk(nfai_ctx_t h, nfai_buf_t x, uint32_t n, float temperature, uint32_t k, uint32_t *ids_out, float *probs_out)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(bx, x);
+    if (n == 0) return fail(NFAI_ERR_INVALID, "topk: n=0");
+    NEED(bx, n, 4);
+    // the upper half of the context scratch (the lower half belongs to argmax / attention, whose ticket words must stay zero)
+    if (topk_work_bytes(n) + 4096 > c->scratch_bytes / 2) return fail(NFAI_ERR_INVALID, "topk: n=%u too large for the context scratch", n);
+    return topk_run(c, static_cast<const float *>(bx->ptr), n, temperature, k, static_cast<char *>(c->scratch) + c->scratch_bytes / 2, ids_out, probs_out);
+}
+
 // ---- fused operators -------------------------------------------------------------------------
 // Scalars the fused kernels read from device memory (so graphs can be replayed) live at the END
 // of the context scratch area when the op-level entry points are used.

@@ -239,6 +239,22 @@ hipError_t launch_add(const float *a, const float *b, float *y, uint32_t n, hipS
 constexpr uint32_t ARGMAX_BLOCKS = 128;
 hipError_t launch_argmax(const float *x, uint32_t n, uint32_t *out_idx, void *partials, uint32_t *pos_inc,
                          uint32_t *ring, uint32_t ring_len, hipStream_t s);
+// top-k candidates of SamplingUtils.TopP on the device (kernels_basic.hip): the k largest of n logits (descending, ties: lower
+// index first) + max(l / T) + sum exp(l / T - max) -> the head of `work` (topk_out_offset(): k floats, at +TOPK_MAX*4 k indices,
+// at +TOPK_MAX*8 M and S).  work: topk_work_bytes(n) bytes, zeroed once.
+constexpr uint32_t TOPK_MAX = 64, TOPK_THREADS = 256, TOPK_NT = 8, TOPK_BLOCKS_MAX = 1024;
+inline uint32_t topk_blocks(uint32_t n)
+{
+    const uint32_t per = TOPK_THREADS * TOPK_NT;  // logits a block can hold in registers
+    const uint32_t need = (n + per - 1) / per, spread = (n + TOPK_THREADS - 1) / TOPK_THREADS;
+    const uint32_t b = need > (spread < 128 ? spread : 128) ? need : (spread < 128 ? spread : 128);  // a vocabulary is spread over >= 128 blocks
+    return b > TOPK_BLOCKS_MAX ? TOPK_BLOCKS_MAX : (b ? b : 1);
+}
+size_t topk_work_bytes(uint32_t n);
+size_t topk_out_offset();
+hipError_t launch_topk(const float *x, uint32_t n, float temperature, uint32_t k, void *work, hipStream_t s);
+// launch + 8k + 8 bytes back + the host half (api.hip); blocking
+int topk_run(Ctx *c, const float *logits_dev, uint32_t n, float temperature, uint32_t k, void *work, uint32_t *ids_out, float *probs_out);
 // per-token prologue: embed row -> x, cos/sin table for the current position
 hipError_t launch_token_begin(const void *table, int type, const uint32_t *tok, float *x, uint32_t E,
                               const float *freqs, float *rope_cs, uint32_t n_freq, const uint32_t *pos_dev,

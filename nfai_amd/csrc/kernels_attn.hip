@@ -97,7 +97,14 @@ __device__ __forceinline__ float row16_sum(float v)
 template <int LPP> __device__ __forceinline__ float pos_sum(float v)
 {
     v = row16_sum(v);
-    if constexpr (LPP == 32) v += __shfl_xor(v, 16);
+    if constexpr (LPP == 32) {
+        // two rows of 16 per position: v_permlane16_swap (gfx950) hands each row its neighbour's total inside the vector ALU.
+        // The shuffle form (ds_bpermute + s_waitcnt lgkmcnt(0) per dot product, twelve in a row with nothing to overlap: seen
+        // in the ISA) cost the score phase ~0.2 us per launch.  Same two addends, same sum.
+        const uint32_t b = __builtin_bit_cast(uint32_t, v);
+        const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);  // r[0]: rows {0,0,2,2}, r[1]: rows {1,1,3,3}
+        v = __builtin_bit_cast(float, (uint32_t)r[0]) + __builtin_bit_cast(float, (uint32_t)r[1]);
+    }
     return v;
 }
 

@@ -282,6 +282,194 @@ hipError_t launch_argmax(const float *x, uint32_t n, uint32_t *out_idx, void *pa
 }
 
 // ---------------------------------------------------------------------------------------------
+// Candidates for SamplingUtils.TopP (SamplingUtils.cs:5-33), the sampler LlamaModel.RunAsync actually calls (LlamaModel.cs:130,
+// 165).  The reference divides all V logits by the temperature, takes a softmax over V, sorts V (index, probability) pairs and
+// keeps the first topK = 40 — on the host, after reading 513 KB of logits back.  Here ONE launch leaves on the device what the
+// rest of TopP needs: the k largest logits with their indices (ties: lower index first, as the stable OrderByDescending :9-12
+// orders equal probabilities), max_i(l_i / T) and sum_i exp(l_i / T - max): 8k + 8 bytes go to the host, which forms the k
+// probabilities, cuts the nucleus and draws (llama.hip: nfai_hip_llama_decode_topk).
+//   level 1: every wave owns a contiguous range of the logits (<= TOPK_NT per lane, in registers) and extracts its k best by k
+//            rounds of [lane-local best -> wave-wide best (DPP inside rows of 16, v_readlane across rows) -> owner retires it];
+//            list, (max, sum of exp) of the range -> workspace (write-through), one ticket per block;
+//   level 2: the block whose ticket is last merges the sorted lists: a thread keeps the heads of its lists, k rounds of
+//            [thread-local best head -> block-wide best -> owner advances]; (max, sum) pairs are combined in fixed order.
+// NaN-free, finite logits assumed (as k_argmax).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool topk_better(float av, uint32_t ai, float bv, uint32_t bi) { return av > bv || (av == bv && ai < bi); }
+
+__device__ __forceinline__ void wave_best(float &v, uint32_t &i)
+{
+#define NFAI_BEST_STEP(CTRL)                                                                                                      \
+    {                                                                                                                             \
+        const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true)); \
+        const uint32_t oi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)i, CTRL, 0xF, 0xF, true);                                 \
+        if (topk_better(ov, oi, v, i)) { v = ov; i = oi; }                                                                        \
+    }
+    NFAI_BEST_STEP(0xB1)   // quad_perm [1,0,3,2]
+    NFAI_BEST_STEP(0x4E)   // quad_perm [2,3,0,1]
+    NFAI_BEST_STEP(0x141)  // row_half_mirror
+    NFAI_BEST_STEP(0x140)  // row_mirror
+#undef NFAI_BEST_STEP
+    // every lane of a row of 16 now holds the row's best; the four rows meet through scalar registers
+    float bv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    uint32_t bi = (uint32_t)__builtin_amdgcn_readlane((int)i, 0);
+#pragma unroll
+    for (int r = 16; r < 64; r += 16) {
+        const float ov = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), r));
+        const uint32_t oi = (uint32_t)__builtin_amdgcn_readlane((int)i, r);
+        if (topk_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    v = bv;
+    i = bi;
+}
+
+struct TopkWork {  // workspace header; the per-wave lists follow (topk_work_bytes)
+    uint32_t ticket, pad[3];
+    float out_v[TOPK_MAX];     // the k largest logits, descending (ties: lower index first)
+    uint32_t out_i[TOPK_MAX];
+    float M, S;                // max_i(l_i / T), sum_i exp(l_i / T - M)
+    float pad2[2];
+};
+
+size_t topk_work_bytes(uint32_t n)
+{
+    const uint32_t nw = topk_blocks(n) * (TOPK_THREADS / 64);
+    return sizeof(TopkWork) + (size_t)nw * (TOPK_MAX * 8 + 8);
+}
+size_t topk_out_offset() { return offsetof(TopkWork, out_v); }
+
+__global__ __launch_bounds__(TOPK_THREADS) void k_topk(const float *x, uint32_t n, float temperature, uint32_t k, TopkWork *w)
+{
+    constexpr uint32_t WPB = TOPK_THREADS / 64;
+    __shared__ float sv[WPB];
+    __shared__ uint32_t si[WPB];
+    __shared__ uint32_t is_last;
+    const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint32_t nw = gridDim.x * WPB, gw = blockIdx.x * WPB + wid;
+    float *cand_v = reinterpret_cast<float *>(w + 1);                       // [nw][TOPK_MAX]
+    uint32_t *cand_i = reinterpret_cast<uint32_t *>(cand_v + (size_t)nw * TOPK_MAX);
+    float *wm = reinterpret_cast<float *>(cand_i + (size_t)nw * TOPK_MAX);  // [nw] range max of l / T
+    float *ws = wm + nw;                                                     // [nw] range sum of exp(l / T - max)
+    // ---- level 1 ----------------------------------------------------------------------------------------------------------
+    const uint32_t cw = (n + nw - 1) / nw, base = gw * cw, end = min(n, base + cw);  // cw <= 64 * TOPK_NT (launch_topk)
+    float v[TOPK_NT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < (int)TOPK_NT; j++) {
+        const uint32_t i = base + j * 64 + lane;
+        v[j] = i < end ? x[i] : -INFINITY;
+        m = fmaxf(m, v[j] / temperature);  // SamplingUtils.cs:7: l / temperature
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < (int)TOPK_NT; j++) sum += (base + j * 64 + lane < end) ? expf(v[j] / temperature - m) : 0.f;  // :38
+    sum = wave_sum(sum);
+    for (uint32_t t = 0; t < k; t++) {
+        float bv = v[0];
+        uint32_t bi = base + lane;
+#pragma unroll
+        for (int j = 1; j < (int)TOPK_NT; j++)
+            if (v[j] > bv) { bv = v[j]; bi = base + j * 64 + lane; }  // strictly greater: the lower index of a tie stays
+        wave_best(bv, bi);
+#pragma unroll
+        for (int j = 0; j < (int)TOPK_NT; j++)
+            if (base + j * 64 + lane == bi) v[j] = -INFINITY;  // the owner retires it
+        if (lane == 0) {
+            __hip_atomic_store(&cand_v[(size_t)gw * TOPK_MAX + t], bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&cand_i[(size_t)gw * TOPK_MAX + t], bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (lane == 0) {
+        __hip_atomic_store(&wm[gw], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ws[gw], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // every storing wave drains, the block meets, ONE lane takes the ticket (the hand-off of k_argmax)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tk = __hip_atomic_fetch_add(&w->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (tk == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!is_last) return;
+    // ---- level 2: k-way merge of the nw sorted lists (agent-scope loads: written by other workgroups) -----------------------
+    constexpr int LPT = (TOPK_BLOCKS_MAX * WPB + TOPK_THREADS - 1) / TOPK_THREADS;  // lists per thread
+    float hv[LPT];
+    uint32_t hi[LPT], hp[LPT];
+#pragma unroll
+    for (int q = 0; q < LPT; q++) {
+        const uint32_t list = threadIdx.x + q * TOPK_THREADS;
+        hp[q] = 0;
+        hv[q] = list < nw ? __hip_atomic_load(&cand_v[(size_t)list * TOPK_MAX], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
+        hi[q] = list < nw ? __hip_atomic_load(&cand_i[(size_t)list * TOPK_MAX], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+    }
+    for (uint32_t t = 0; t < k; t++) {
+        float bv = hv[0];
+        uint32_t bi = hi[0];
+#pragma unroll
+        for (int q = 1; q < LPT; q++)
+            if (topk_better(hv[q], hi[q], bv, bi)) { bv = hv[q]; bi = hi[q]; }
+        wave_best(bv, bi);
+        if (lane == 0) { sv[wid] = bv; si[wid] = bi; }
+        __syncthreads();
+        bv = sv[0];
+        bi = si[0];
+#pragma unroll
+        for (uint32_t q = 1; q < WPB; q++)
+            if (topk_better(sv[q], si[q], bv, bi)) { bv = sv[q]; bi = si[q]; }
+        if (threadIdx.x == 0) { w->out_v[t] = bv; w->out_i[t] = bi; }
+#pragma unroll
+        for (int q = 0; q < LPT; q++) {
+            const uint32_t list = threadIdx.x + q * TOPK_THREADS;
+            if (list < nw && hi[q] == bi && hv[q] == bv) {  // indices are unique: this thread's list holds the winner
+                hp[q]++;
+                const bool more = hp[q] < k;
+                hv[q] = more ? __hip_atomic_load(&cand_v[(size_t)list * TOPK_MAX + hp[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
+                hi[q] = more ? __hip_atomic_load(&cand_i[(size_t)list * TOPK_MAX + hp[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+            }
+        }
+        __syncthreads();  // sv / si are rewritten by the next round
+    }
+    // (max, sum of exp): M = max over the ranges, S = sum_w s_w * exp(m_w - M), thread-strided then a fixed tree
+    float M = -INFINITY;
+    for (uint32_t q = threadIdx.x; q < nw; q += TOPK_THREADS) M = fmaxf(M, __hip_atomic_load(&wm[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    M = wave_max(M);
+    if (lane == 0) sv[wid] = M;
+    __syncthreads();
+    M = sv[0];
+#pragma unroll
+    for (uint32_t q = 1; q < WPB; q++) M = fmaxf(M, sv[q]);
+    __syncthreads();
+    float S = 0.f;
+    for (uint32_t q = threadIdx.x; q < nw; q += TOPK_THREADS) {
+        const float mq = __hip_atomic_load(&wm[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float sq = __hip_atomic_load(&ws[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        S += sq * expf(mq - M);
+    }
+    S = wave_sum(S);
+    if (lane == 0) sv[wid] = S;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        S = sv[0];
+#pragma unroll
+        for (uint32_t q = 1; q < WPB; q++) S += sv[q];
+        w->M = M;
+        w->S = S;
+        __hip_atomic_store(&w->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm (stream-ordered with the next launch)
+    }
+}
+
+hipError_t launch_topk(const float *x, uint32_t n, float temperature, uint32_t k, void *work, hipStream_t s)
+{
+    if (n == 0 || k == 0 || k > TOPK_MAX || k > n || !(temperature > 0.f)) return hipErrorInvalidValue;
+    const uint32_t blocks = topk_blocks(n);
+    if ((uint64_t)blocks * TOPK_THREADS * TOPK_NT < n) return hipErrorInvalidValue;  // more logits than TOPK_BLOCKS_MAX blocks hold
+    k_topk<<<blocks, TOPK_THREADS, 0, s>>>(x, n, temperature, k, reinterpret_cast<TopkWork *>(work));
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Per-token prologue of the fused path (one launch): embedding row -> x (TokenEmbedShader), and
 // the cos/sin table of the current position, shared by every layer's RoPE epilogue
 // (RoPEShader.cs:254-256 recomputes cos/sin per element per layer).

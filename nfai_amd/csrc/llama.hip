@@ -61,6 +61,7 @@ struct Model {
     uint32_t *d_pos = nullptr, *d_tok = nullptr, *d_ring = nullptr;
     float *d_freqs = nullptr, *d_ropecs = nullptr;
     void *d_argmax_part = nullptr;
+    void *d_topk = nullptr;          // workspace of the top-k candidate launch (allocated by the first nfai_hip_llama_decode_topk)
     float *d_attn_part = nullptr;
     // activations
     float *x = nullptr, *h = nullptr, *q = nullptr, *att = nullptr, *act = nullptr, *logits = nullptr;
@@ -733,7 +734,7 @@ NFAI_API int32_t nfai_hip_llama_destroy(nfai_model_t h)
         free_t(L.ffn_norm); free_t(L.wgate); free_t(L.wup); free_t(L.wdown);
         hipFree(L.kcache); hipFree(L.vcache);
     }
-    void *ptrs[] = {m->d_engparams, m->d_gran, m->d_epoch, m->d_engerr, m->d_pos, m->d_tok, m->d_ring, m->d_freqs, m->d_ropecs, m->d_argmax_part, m->d_attn_part, m->x, m->h,
+    void *ptrs[] = {m->d_topk, m->d_engparams, m->d_gran, m->d_epoch, m->d_engerr, m->d_pos, m->d_tok, m->d_ring, m->d_freqs, m->d_ropecs, m->d_argmax_part, m->d_attn_part, m->x, m->h,
                     m->q, m->att, m->act, m->logits, m->xn, m->qraw, m->scores, m->wts, m->proj, m->gate, m->up};
     for (void *p : ptrs) if (p) hipFree(p);
     void *pfp[] = {m->pf.toks, m->pf.X, m->pf.H1, m->pf.Q, m->pf.K, m->pf.V, m->pf.ATT, m->pf.G, m->pf.U, m->pf.SC,
@@ -908,6 +909,25 @@ NFAI_API int32_t nfai_hip_llama_decode_step(nfai_model_t h, uint32_t token, floa
     HIP_TRY(hipStreamSynchronize(s));
     if (m->h_pin[1]) return engine_failed(m, m->h_pin[1]);
     if (argmax) *argmax = m->h_pin[0];
+    return NFAI_OK;
+}
+
+// One token, then the candidates of the reference's DEFAULT sampler on the device (LlamaModel.cs:128-130,165: TopP over V logits
+// read back to the host; here 8k + 8 bytes come back instead of 513 KB).
+NFAI_API int32_t nfai_hip_llama_decode_topk(nfai_model_t h, uint32_t token, float temperature, uint32_t k, uint32_t *ids_out, float *probs_out)
+{
+    MODEL_OR_FAIL(m, h);
+    NEED_FINAL(m);
+    if (!(m->first_stage && m->last_stage)) return fail(NFAI_ERR_STATE, "decode_topk: model is a pipeline stage");
+    if (token >= m->d.V) return fail(NFAI_ERR_INVALID, "decode_topk: token %u >= vocab %u", token, m->d.V);
+    if (!m->d_topk) DALLOC(m->d_topk, topk_work_bytes(m->d.V));
+    int rc = set_token_async(m, token);
+    if (rc) return rc;
+    if ((rc = run_token(m))) return rc;
+    HIP_TRY(hipMemcpyAsync(m->h_pin + 1, m->d_engerr, 4, hipMemcpyDeviceToHost, m->ctx->stream));
+    rc = topk_run(m->ctx, m->logits, m->d.V, temperature, k, m->d_topk, ids_out, probs_out);  // synchronises
+    if (rc) return rc;
+    if (m->h_pin[1]) return engine_failed(m, m->h_pin[1]);
     return NFAI_OK;
 }
 

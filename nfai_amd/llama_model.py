@@ -77,6 +77,28 @@ class SamplingUtils:
         return int(order[min(idx, len(order) - 1)])
 
     @staticmethod
+    def TopPFromCandidates(ids: np.ndarray, probs: np.ndarray, topP: float = 0.95, rand: float | None = None,
+                           rng: np.random.Generator | None = None) -> int:
+        """SamplingUtils.cs:14-31 on the (index, probability) pairs `.Take(topK)` leaves (:13) — what
+        nfai_hip_llama_decode_topk returns: nucleus cut (the element that crosses topP is kept), renormalise, draw.
+        `rand` stands in for Random.Shared.NextSingle() (:24)."""
+        cumulative = np.float32(0.0)
+        keep = 0
+        for p in probs:
+            cumulative = np.float32(cumulative + np.float32(p))
+            keep += 1
+            if cumulative >= np.float32(topP):
+                break
+        total = np.float32(np.sum(probs[:keep], dtype=np.float64))  # Enumerable.Sum over floats accumulates in double
+        r = np.float32(rand) if rand is not None else (rng or np.random.default_rng()).random(dtype=np.float32)
+        running = np.float32(0.0)
+        for i in range(keep):
+            running = np.float32(running + np.float32(probs[i]) / total)
+            if r < running:
+                return int(ids[i])
+        return int(ids[keep - 1])
+
+    @staticmethod
     def ArgMax(values: np.ndarray) -> int:
         return int(np.argmax(values))  # first maximum, as values.ToList().IndexOf(max) (:56)
 
@@ -143,6 +165,15 @@ class LlamaModel:
         call("nfai_hip_llama_decode_step", self.handle, int(token),
              logits.ctypes.data_as(C.POINTER(C.c_float)) if want_logits else None, C.byref(am))
         return logits, am.value
+
+    def StepTopK(self, token: int, temperature: float = 0.5, topK: int = 40):
+        """One token, then the candidates of SamplingUtils.TopP formed on the device (SamplingUtils.cs:5-13): (ids[topK],
+        probs[topK]); 8*topK + 8 bytes come back instead of V floats."""
+        ids = np.empty(topK, np.uint32)
+        probs = np.empty(topK, np.float32)
+        call("nfai_hip_llama_decode_topk", self.handle, int(token), float(temperature), int(topK),
+             ids.ctypes.data_as(C.POINTER(C.c_uint32)), probs.ctypes.data_as(C.POINTER(C.c_float)))
+        return ids, probs
 
     def Greedy(self, first_token: int, n_steps: int) -> np.ndarray:
         out = np.empty(n_steps, np.uint32)
@@ -228,16 +259,21 @@ class LlamaModel:
             raise RuntimeError("RunAsync needs a tokenizer (nfai_amd.tokenizer.Tokenizer(metadata))")
         tokenIds = self.tokenizer.Tokenize(prompt, addBos=self.firstInput)
         self.firstInput = False
-        logits = None
-        for tok in tokenIds:  # prompt, one token at a time (:103-126)
-            logits, _ = self.Step(tok)
-        pick = SamplingUtils.ArgMax if greedy else (lambda v: SamplingUtils.TopP(v, rng=rng))
-        tk = pick(logits)
+        # greedy: ArgMax on the device (SamplingUtils.cs:43-57).  Otherwise the reference's default (LlamaModel.cs:130,165):
+        # TopP(temperature 0.5, topP 0.95, topK 40) — the softmax over V and the top-40 are formed on the device
+        # (nfai_hip_llama_decode_topk), the nucleus cut and the draw here; the V logits never cross PCIe.
+        def step(tok):
+            if greedy:
+                return self.Step(tok, want_logits=False)[1]
+            ids, probs = self.StepTopK(tok)
+            return SamplingUtils.TopPFromCandidates(ids, probs, rng=rng)
+        for tok in tokenIds[:-1]:  # prompt, one token at a time (:103-126); only the last token's output is sampled (:128-130)
+            self.Step(tok, want_logits=False)
+        tk = step(tokenIds[-1])
         yield self.tokenizer.Detokenize([tk])
         n = 1
         while tk != self.tokenizer.EosTokenId and (max_tokens is None or n < max_tokens):
-            logits, _ = self.Step(tk)
-            tk = pick(logits)
+            tk = step(tk)
             n += 1
             if tk != self.tokenizer.EosTokenId:
                 yield self.tokenizer.Detokenize([tk])

@@ -14,7 +14,7 @@ _SRC = os.path.join(_HERE, "nfai_oracle.c")
 
 __all__ = [
     "build", "lib", "embed", "rmsnorm", "gemv", "gemv_f16w", "rope_freqs", "rope", "attn_scores",
-    "attn_softmax", "attn_wsum", "silu", "mul", "add", "argmax", "widen_f16", "narrow_f16",
+    "attn_softmax", "attn_wsum", "silu", "mul", "add", "argmax", "topp", "widen_f16", "narrow_f16",
     "dequant_q4k", "dequant_q6k", "quantize_q4k", "quantize_q6k", "LlamaDesc", "OracleLlama",
     "num_threads", "set_num_threads", "Q4K_BYTES", "Q6K_BYTES", "QK_K",
 ]
@@ -82,6 +82,7 @@ def lib() -> C.CDLL:
             "orc_mul": (None, [f32p, f32p, f32p, u32]),
             "orc_add": (None, [f32p, f32p, f32p, u32]),
             "orc_argmax": (u32, [f32p, u32]),
+            "orc_topp": (u32, [f32p, u32, f32, f32, u32, f32, C.POINTER(C.c_uint32), f32p, C.POINTER(C.c_uint32)]),
             "orc_dequant_q4k": (None, [u8p, f32p, sz]),
             "orc_dequant_q6k": (None, [u8p, f32p, sz]),
             "orc_quantize_q4k": (None, [f32p, u8p, sz]),
@@ -233,6 +234,18 @@ def add(a, b) -> np.ndarray:
 def argmax(v) -> int:
     v = _f32(v)
     return int(lib().orc_argmax(_p(v), v.size))
+
+
+def topp(values, temperature: float = 0.5, topP: float = 0.95, topK: int = 40, rand: float = 0.0):
+    """SamplingUtils.TopP (SamplingUtils.cs:5-33) with the random draw given: (token, ids[topK], probs[topK], n_kept)."""
+    v = _f32(values)
+    k = min(int(topK), v.size)
+    ids = np.empty(k, np.uint32)
+    probs = np.empty(k, np.float32)
+    kept = C.c_uint32()
+    tok = lib().orc_topp(_p(v), v.size, float(temperature), float(topP), k, float(rand),
+                         ids.ctypes.data_as(C.POINTER(C.c_uint32)), _p(probs), C.byref(kept))
+    return int(tok), ids, probs, int(kept.value)
 
 
 def dequant_q4k(blocks: np.ndarray, n_weights: int) -> np.ndarray:

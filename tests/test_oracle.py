@@ -149,3 +149,50 @@ def test_layer_slices_compose():
         h = b.layers(h, 1, dims.L)
         b.advance()
         np.testing.assert_array_equal(h, a.hidden())
+
+
+def _topp_fp64(values, temperature, topP, topK, rand):
+    """Independent evaluation of SamplingUtils.TopP (SamplingUtils.cs:5-33) in NumPy: float32 element arithmetic as the C#
+    code has it, double accumulation where Enumerable.Sum is used."""
+    scaled = values.astype(np.float32) / np.float32(temperature)
+    e = np.exp(scaled - scaled.max()).astype(np.float32)
+    probs = e / np.float32(e.sum(dtype=np.float64))
+    order = np.argsort(-probs, kind="stable")[:topK]
+    cum, keep = np.float32(0), 0
+    for i in order:
+        cum = np.float32(cum + probs[i])
+        keep += 1
+        if cum >= np.float32(topP):
+            break
+    kept = order[:keep]
+    total = np.float32(probs[kept].sum(dtype=np.float64))
+    running = np.float32(0)
+    for i in kept:
+        running = np.float32(running + probs[i] / total)
+        if np.float32(rand) < running:
+            return int(i), order, probs[order], keep
+    return int(kept[-1]), order, probs[order], keep
+
+
+@pytest.mark.parametrize("n,seed", [(1000, 1), (128256, 2), (50, 3)])
+def test_topp_restatement(n, seed):
+    """orc_topp (the restatement of the reference's default sampler) against an independent NumPy evaluation and against the
+    product's host-side sampler; stable order of equal probabilities; the draw as an argument."""
+    from nfai_amd.llama_model import SamplingUtils
+    r = np.random.Generator(np.random.PCG64(seed))
+    v = (3.0 * r.standard_normal(n)).astype(np.float32)
+    top = v.max()
+    v[[min(n - 1, 41), 7]] = top + 1.0  # two equal maxima: index 7 first (stable OrderByDescending, SamplingUtils.cs:9-12)
+    k = min(40, n)
+    for rand in (0.0, 0.05, 0.3, 0.5, 0.77, 0.949, 0.95, 0.999999):
+        tok, ids, probs, kept = orc.topp(v, 0.5, 0.95, k, rand)
+        tok2, ids2, probs2, kept2 = _topp_fp64(v, 0.5, 0.95, k, rand)
+        assert tok == tok2 and kept == kept2
+        np.testing.assert_array_equal(ids, ids2.astype(np.uint32))
+        np.testing.assert_allclose(probs, probs2, rtol=2e-6)
+        assert ids[0] == 7 and ids[1] == min(n - 1, 41)
+        assert SamplingUtils.TopPFromCandidates(ids, probs, 0.95, rand=rand) == tok   # the host half the product keeps
+    # temperature 1, a flat distribution: the nucleus needs all topK candidates
+    flat = np.zeros(n, np.float32)
+    tok, ids, probs, kept = orc.topp(flat, 1.0, 0.95, k, 0.5)
+    assert kept == k and list(ids) == list(range(k)) and tok == _topp_fp64(flat, 1.0, 0.95, k, 0.5)[0] and tok in (19, 20)
