@@ -178,6 +178,10 @@ int32_t nfai_hip_gemm_kq(nfai_ctx_t ctx, nfai_buf_t A_f16, nfai_buf_t W, int32_t
                          uint32_t N, uint32_t K);
 int32_t nfai_hip_gemv_fused(nfai_ctx_t ctx, nfai_buf_t W, int32_t w_type, nfai_buf_t x, nfai_buf_t gamma,
                             float eps, nfai_buf_t res, nfai_buf_t y, uint32_t N, uint32_t K);
+/* output RMSNorm (gamma may be 0) -> lm_head GEMV -> SamplingUtils.ArgMax in ONE launch (LlamaModel.cs:123-125, SamplingUtils.cs:43-57):
+ * V logits and the first index of their maximum (one uint32 in out_idx).  F16 / F32 tables, and Q4_K / Q6_K tables with V %% 16 == 0. */
+int32_t nfai_hip_lmhead_argmax(nfai_ctx_t ctx, nfai_buf_t W, int32_t w_type, nfai_buf_t x, nfai_buf_t gamma, float eps,
+                               nfai_buf_t logits, nfai_buf_t out_idx, uint32_t V, uint32_t E);
 /* RMSNorm -> Wgate, Wup GEMVs -> SiLU(gate) * up (TransformerBlock.cs:163-171 in one launch). */
 int32_t nfai_hip_gemv_gateup_silu(nfai_ctx_t ctx, nfai_buf_t Wgate, nfai_buf_t Wup, int32_t w_type,
                                   nfai_buf_t x, nfai_buf_t gamma, float eps, nfai_buf_t y,

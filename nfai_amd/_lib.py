@@ -79,6 +79,7 @@ SIGNATURES = {
     "nfai_hip_topk": [H, H, u32, f32, u32, C.POINTER(u32), C.POINTER(f32)],
     "nfai_hip_attn_decode": [H, H, H, H, H, u32, u32, u32, u32, u32, i32],
     "nfai_hip_gemv_fused": [H, H, i32, H, H, f32, H, H, u32, u32],
+    "nfai_hip_lmhead_argmax": [H, H, i32, H, H, f32, H, H, u32, u32],
     "nfai_hip_gemv_gateup_silu": [H, H, H, i32, H, H, f32, H, u32, u32],
     "nfai_hip_gemv_qkv_rope": [H, H, H, H, i32, H, H, f32, H, u32, H, H, H, u32, u32, u32, u32, i32, u32],
     "nfai_hip_engine_block": [H, H, H, H, H, H, H, H, f32, u32, u32, u32, H, H, H, H, H, u32, H, H, H, u32, u32, u32, u32, i32, H, H],

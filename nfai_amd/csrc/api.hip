@@ -777,6 +777,43 @@ NFAI_API int32_t nfai_hip_gemv_fused(nfai_ctx_t h, nfai_buf_t W, int32_t type, n
     return gemv_common(c, a, __func__);
 }
 
+// output RMSNorm -> lm_head -> SamplingUtils.ArgMax in ONE launch (LlamaModel.cs:123-125 + SamplingUtils.cs:43-57):
+// logits (V floats) and the first index of their maximum (one uint32).  The model's token graph ends with this launch.
+NFAI_API int32_t nfai_hip_lmhead_argmax(nfai_ctx_t h, nfai_buf_t W, int32_t type, nfai_buf_t x, nfai_buf_t gamma, float eps, nfai_buf_t logits,
+                                        nfai_buf_t out_idx, uint32_t V, uint32_t E)
+{
+    CTX_OR_FAIL(c, h);
+    BUF_OR_FAIL(bw, W);
+    BUF_OR_FAIL(bx, x);
+    BUF_OR_FAIL(by, logits);
+    BUF_OR_FAIL(bo, out_idx);
+    Buf *bg = gamma ? buf_of(gamma) : nullptr;
+    if (gamma && !bg) return fail(NFAI_ERR_INVALID, "lmhead_argmax: invalid gamma handle");
+    const uint64_t rb = weight_row_bytes(type, E);
+    if (rb == 0) return fail(NFAI_ERR_UNSUPPORTED, "lmhead_argmax: ggml type %d with E=%u is not supported", type, E);
+    NEED(bw, (uint64_t)V * rb, 1);
+    NEED(bx, E, 4);
+    NEED(by, V, 4);
+    NEED(bo, 1, 4);
+    if (bg) NEED(bg, E, 4);
+    GemvArgs a;
+    a.W[0] = bw->ptr;
+    a.seg_rows[0] = V;
+    { int rc = resolve_layout(__func__, bw, type, V, &a.w_type); if (rc) return rc; }
+    if (a.w_type != NFAI_F16 && a.w_type != NFAI_F32 && a.w_type != NFAI_Q4_K_T16 && a.w_type != NFAI_Q6_K_T16)
+        return fail(NFAI_ERR_UNSUPPORTED, "lmhead_argmax: K-quant tables need a row count that is a multiple of 16 (V=%u)", V);
+    a.x = static_cast<const float *>(bx->ptr);
+    a.gamma = bg ? static_cast<const float *>(bg->ptr) : nullptr;
+    a.eps = eps;
+    a.K = E;
+    a.mode = GEMV_PLAIN;
+    a.y = static_cast<float *>(by->ptr);
+    // workspace: the context scratch behind k_argmax's partials (ticket word zero between launches)
+    a.argmax_part = static_cast<char *>(c->scratch) + 4096;
+    a.argmax_out = static_cast<uint32_t *>(bo->ptr);
+    return gemv_common(c, a, __func__);
+}
+
 NFAI_API int32_t nfai_hip_gemv_gateup_silu(nfai_ctx_t h, nfai_buf_t Wg, nfai_buf_t Wu, int32_t type, nfai_buf_t x,
                                            nfai_buf_t gamma, float eps, nfai_buf_t y, uint32_t F, uint32_t K)
 {

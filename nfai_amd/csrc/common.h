@@ -100,7 +100,14 @@ struct GemvArgs {
     const uint32_t *pos_dev = nullptr;  // current position (device scalar)
     uint32_t n_cu = 256;
     bool prefetch_only = false;  // side-stream launch that only touches the first two steps of every wave's weights
+    // GEMV_PLAIN only: SamplingUtils.ArgMax over the N outputs in the same launch (the lm_head): argmax_part = workspace of
+    // argmax_fused_bytes() bytes, zeroed once; the first index of the maximum -> argmax_out; then, if argmax_pos_inc != nullptr, the
+    // end-of-token bookkeeping of launch_argmax (ring[pos % ring_len] = token, ++pos)
+    void *argmax_part = nullptr;
+    uint32_t *argmax_out = nullptr, *argmax_pos_inc = nullptr, *argmax_ring = nullptr;
+    uint32_t argmax_ring_len = 0;
 };
+constexpr size_t argmax_fused_bytes() { return 1024 * 8 + 256; }  // [1024] values | [1024] indices | ticket
 enum GemvMode { GEMV_PLAIN = 0, GEMV_RESIDUAL = 1, GEMV_QKV_ROPE = 2, GEMV_GATEUP = 3 };
 
 // Internal weight-type codes of the T16 layouts (kernels_gemv_kqm.hip): same bytes as the ggml type, rows
@@ -308,6 +315,19 @@ __device__ __forceinline__ float wave_max(float v)
     return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
+// Sum over the four rows of 16 lanes (lane r, r + 16, r + 32, r + 48), every lane gets it: (v[r] + v[r+16]) + (v[r+32] + v[r+48]),
+// the order of `v += shfl_xor(v, 16); v += shfl_xor(v, 32)`, but inside the vector ALU (gfx950: v_permlane16_swap / v_permlane32_swap)
+// instead of two dependent ds_bpermute round trips through the LDS crossbar with an s_waitcnt each.
+__device__ __forceinline__ float rows4_sum(float v)
+{
+    const uint32_t b = __builtin_bit_cast(uint32_t, v);
+    const auto r16 = __builtin_amdgcn_permlane16_swap(b, b, false, false);  // [0]: rows {0,0,2,2}, [1]: rows {1,1,3,3}
+    const float t = __builtin_bit_cast(float, (uint32_t)r16[0]) + __builtin_bit_cast(float, (uint32_t)r16[1]);
+    const uint32_t tb = __builtin_bit_cast(uint32_t, t);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(tb, tb, false, false);  // [0]: halves {lo, lo}, [1]: halves {hi, hi}
+    return __builtin_bit_cast(float, (uint32_t)r32[0]) + __builtin_bit_cast(float, (uint32_t)r32[1]);
+}
+
 // Sum within aligned groups of `width` lanes (power of two <= 64); every lane of the group gets it.
 template <int width>
 __device__ __forceinline__ float group_sum(float v)
@@ -343,6 +363,93 @@ __device__ __forceinline__ float dot8_f16(u32x4 w, f32x4 x0, f32x4 x1, float acc
     acc = fmaf(h2f_lo(w[3]), x1[2], acc);
     acc = fmaf(h2f_hi(w[3]), x1[3], acc);
     return acc;
+}
+
+// ---- "first index of the largest value" across lanes / waves / workgroups (SamplingUtils.ArgMax, SamplingUtils.cs:55-56: values.Max()
+//      then IndexOf: the LOWEST index among equal maxima) ---------------------------------------------------------------------------
+__device__ __forceinline__ bool topk_better(float av, uint32_t ai, float bv, uint32_t bi) { return av > bv || (av == bv && ai < bi); }
+
+__device__ __forceinline__ void wave_best(float &v, uint32_t &i)
+{
+#define NFAI_BEST_STEP(CTRL)                                                                                                      \
+    {                                                                                                                             \
+        const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true)); \
+        const uint32_t oi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)i, CTRL, 0xF, 0xF, true);                                 \
+        if (topk_better(ov, oi, v, i)) { v = ov; i = oi; }                                                                        \
+    }
+    NFAI_BEST_STEP(0xB1)   // quad_perm [1,0,3,2]
+    NFAI_BEST_STEP(0x4E)   // quad_perm [2,3,0,1]
+    NFAI_BEST_STEP(0x141)  // row_half_mirror
+    NFAI_BEST_STEP(0x140)  // row_mirror
+#undef NFAI_BEST_STEP
+    // every lane of a row of 16 now holds the row's best; the four rows meet through scalar registers
+    float bv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    uint32_t bi = (uint32_t)__builtin_amdgcn_readlane((int)i, 0);
+#pragma unroll
+    for (int r = 16; r < 64; r += 16) {
+        const float ov = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), r));
+        const uint32_t oi = (uint32_t)__builtin_amdgcn_readlane((int)i, r);
+        if (topk_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    v = bv;
+    i = bi;
+}
+
+
+// ArgMax folded into the launch that produces the values (the lm_head GEMV): every thread arrives with the best (value, index) it
+// has finished itself ((-inf, 0xFFFFFFFF) if none); the workgroup's best goes to part[blockIdx.x] (write-through), ONE lane takes a
+// ticket, and the workgroup whose ticket is last combines the partials — (value desc, index asc) is a total order, so the result does
+// not depend on which workgroup that is — and does the end-of-token bookkeeping of k_argmax: token fed back, ring, position.
+// lds: 34 words no other code of the kernel touches.  Called by ALL threads of the workgroup, once, at the end of the kernel.
+struct ArgmaxFused {
+    float *part_v;        // [gridDim.x]
+    uint32_t *part_i;     // [gridDim.x]
+    uint32_t *ticket;     // zero between launches
+    uint32_t *out_idx, *pos_inc, *ring;
+    uint32_t ring_len;
+};
+constexpr uint32_t ARGMAX_FUSED_MAX_BLOCKS = 1024;
+__device__ __forceinline__ void argmax_fused_tail(float bv, uint32_t bi, const ArgmaxFused &t, uint32_t *lds)
+{
+    float *sv = reinterpret_cast<float *>(lds);
+    uint32_t *si = lds + 16, *last = lds + 32;
+    const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    wave_best(bv, bi);
+    if (lane == 0) { sv[wid] = bv; si[wid] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t w = 1; w < nw; w++)
+            if (topk_better(sv[w], si[w], bv, bi)) { bv = sv[w]; bi = si[w]; }
+        __hip_atomic_store(&t.part_v[blockIdx.x], bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&t.part_i[blockIdx.x], bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t tk = __hip_atomic_fetch_add(t.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last[0] = (tk == gridDim.x - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last[0] == 0u) return;
+    bv = -INFINITY;
+    bi = 0xFFFFFFFFu;
+    for (uint32_t b = threadIdx.x; b < gridDim.x; b += blockDim.x) {
+        const float v = __hip_atomic_load(&t.part_v[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t i = __hip_atomic_load(&t.part_i[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (topk_better(v, i, bv, bi)) { bv = v; bi = i; }
+    }
+    wave_best(bv, bi);
+    __syncthreads();
+    if (lane == 0) { sv[wid] = bv; si[wid] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t w = 1; w < nw; w++)
+            if (topk_better(sv[w], si[w], bv, bi)) { bv = sv[w]; bi = si[w]; }
+        t.out_idx[0] = bi;
+        __hip_atomic_store(t.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm (stream-ordered with the next launch)
+        if (t.pos_inc) {
+            const uint32_t pp = t.pos_inc[0];
+            if (t.ring) t.ring[pp % t.ring_len] = bi;
+            t.pos_inc[0] = pp + 1;
+        }
+    }
 }
 
 #ifdef NFAI_STAMPS

@@ -295,34 +295,6 @@ hipError_t launch_argmax(const float *x, uint32_t n, uint32_t *out_idx, void *pa
 //            [thread-local best head -> block-wide best -> owner advances]; (max, sum) pairs are combined in fixed order.
 // NaN-free, finite logits assumed (as k_argmax).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool topk_better(float av, uint32_t ai, float bv, uint32_t bi) { return av > bv || (av == bv && ai < bi); }
-
-__device__ __forceinline__ void wave_best(float &v, uint32_t &i)
-{
-#define NFAI_BEST_STEP(CTRL)                                                                                                      \
-    {                                                                                                                             \
-        const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true)); \
-        const uint32_t oi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)i, CTRL, 0xF, 0xF, true);                                 \
-        if (topk_better(ov, oi, v, i)) { v = ov; i = oi; }                                                                        \
-    }
-    NFAI_BEST_STEP(0xB1)   // quad_perm [1,0,3,2]
-    NFAI_BEST_STEP(0x4E)   // quad_perm [2,3,0,1]
-    NFAI_BEST_STEP(0x141)  // row_half_mirror
-    NFAI_BEST_STEP(0x140)  // row_mirror
-#undef NFAI_BEST_STEP
-    // every lane of a row of 16 now holds the row's best; the four rows meet through scalar registers
-    float bv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-    uint32_t bi = (uint32_t)__builtin_amdgcn_readlane((int)i, 0);
-#pragma unroll
-    for (int r = 16; r < 64; r += 16) {
-        const float ov = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), r));
-        const uint32_t oi = (uint32_t)__builtin_amdgcn_readlane((int)i, r);
-        if (topk_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
-    }
-    v = bv;
-    i = bi;
-}
-
 struct TopkWork {  // workspace header; the per-wave lists follow (topk_work_bytes)
     uint32_t ticket, pad[3];
     float out_v[TOPK_MAX];     // the k largest logits, descending (ties: lower index first)

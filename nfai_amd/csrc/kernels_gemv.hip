@@ -39,6 +39,7 @@ struct GemvParams {
     const uint32_t *pos;
     int kv_f16;
     uint32_t prefetch_only;  // 1: touch the first two steps of every wave's weights (default cache policy) and exit
+    ArgmaxFused am;          // GEMV_PLAIN: first index of the largest output, taken in this launch (am.ticket == nullptr: off)
     NFAI_STAMP_PARAM
 };
 
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
     // x float4s held per thread across the prologue: 4 covers K <= 16*blockDim (every RMSNorm'd
     // input: K = n_embd), 16 covers K <= 64*blockDim (the FFN down projection, K = ffn length)
     constexpr int XN = NORM ? 4 : 16;
-    extern __shared__ __attribute__((aligned(16))) float xs[];  // KC*64*EPL floats, then 16 for reductions
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // KC*64*EPL floats, then 16 for reductions, then 48 words of the fused ArgMax
 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t nwaves = blockDim.x >> 6;
@@ -320,6 +321,8 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.f;
 
+    float best_v = -INFINITY;
+    uint32_t best_i = 0xFFFFFFFFu;
     StepWalk cw;  // compute walker
     auto consume = [&](u32x4 (&buf)[R][U]) {
 #pragma unroll
@@ -334,8 +337,12 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
             for (int q = 0; q < UPW; q++) {
                 const uint32_t u = u_begin + cw.g * UPW + q;
                 // lane q finishes unit q (uniform values; spreads the stores over lanes)
-                if (lane == (uint32_t)q && u < u_end)
+                if (lane == (uint32_t)q && u < u_end) {
                     epilogue<MODE>(p, u, acc[q * RPU], RPU == 2 ? acc[q * RPU + RPU - 1] : 0.f, e0, e1, pos_v);
+                    if constexpr (MODE == GEMV_PLAIN) {  // running best of the rows this lane has finished (lm_head + ArgMax)
+                        if (topk_better(acc[q], u, best_v, best_i)) { best_v = acc[q]; best_i = u; }
+                    }
+                }
             }
 #pragma unroll
             for (int r = 0; r < R; r++) acc[r] = 0.f;
@@ -379,6 +386,10 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
         consume(bufB);
     } else if (rem == 1) {
         consume(bufA);
+    }
+    if constexpr (MODE == GEMV_PLAIN) {
+        // SamplingUtils.ArgMax over the outputs in the same launch (block-uniform: a kernel argument)
+        if (p.am.ticket != nullptr) argmax_fused_tail(best_v, best_i, p.am, reinterpret_cast<uint32_t *>(xs + kpad + 16));
     }
 #ifdef NFAI_STAMPS
     STAMP(4);  // last FMA, reduction and epilogue stores issued
@@ -446,7 +457,7 @@ static GemvPlan plan_gemv(uint32_t NU, uint32_t K, int epl, int rpu, uint32_t n_
     pl.upw = upw;
     pl.grid = grid;
     pl.block = wpb * 64;
-    pl.lds_bytes = (kc * ce + 16) * 4;
+    pl.lds_bytes = (kc * ce + 16 + 48) * 4;
     return pl;
 }
 
@@ -538,8 +549,15 @@ hipError_t launch_gemv(const GemvArgs &a, hipStream_t s)
     p.pos = a.pos_dev;
     p.kv_f16 = a.kv_type == NFAI_F16;
     p.prefetch_only = a.prefetch_only ? 1u : 0u;
+    if (a.argmax_part) {
+        if (a.mode != GEMV_PLAIN || !a.argmax_out) return hipErrorInvalidValue;
+        p.am.part_v = static_cast<float *>(a.argmax_part);
+        p.am.part_i = reinterpret_cast<uint32_t *>(p.am.part_v + ARGMAX_FUSED_MAX_BLOCKS);
+        p.am.ticket = p.am.part_i + ARGMAX_FUSED_MAX_BLOCKS;
+        p.am.out_idx = a.argmax_out; p.am.pos_inc = a.argmax_pos_inc; p.am.ring = a.argmax_ring; p.am.ring_len = a.argmax_ring_len;
+    }
     const GemvPlan pl = plan_gemv(p.NU, a.K, epl, rpu, a.n_cu, a.gamma != nullptr, a.mode);
-    if (!pl.ok) return hipErrorInvalidValue;
+    if (!pl.ok || (a.argmax_part && pl.grid > ARGMAX_FUSED_MAX_BLOCKS)) return hipErrorInvalidValue;
     p.KC = (a.K + 64 * epl - 1) / (64 * epl);
     if (pl.lds_bytes > 160 * 1024) return hipErrorInvalidValue;
     {

@@ -129,11 +129,15 @@ __device__ __forceinline__ KqmPre kqm_preload(const KqmParams &p, uint32_t u, ui
 
 // lanes 0..15 hold the 16 rows of the unit (a0; a1 = up row for GATEUP)
 template <int MODE>
-__device__ __forceinline__ void kqm_epilogue(const KqmParams &p, uint32_t u, uint32_t lane, float a0, float a1, const KqmPre &pre)
+__device__ __forceinline__ void kqm_epilogue(const KqmParams &p, uint32_t u, uint32_t lane, float a0, float a1, const KqmPre &pre, float &best_v,
+                                             uint32_t &best_i)
 {
     const uint32_t r = lane & 15;
     if constexpr (MODE == GEMV_PLAIN) {
-        if (lane < 16) p.y[u * 16 + r] = a0;
+        if (lane < 16) {
+            p.y[u * 16 + r] = a0;
+            if (topk_better(a0, u * 16 + r, best_v, best_i)) { best_v = a0; best_i = u * 16 + r; }  // lm_head + ArgMax in one launch
+        }
     } else if constexpr (MODE == GEMV_RESIDUAL) {
         if (lane < 16) p.y[u * 16 + r] = pre.res + a0;
     } else if constexpr (MODE == GEMV_GATEUP) {
@@ -271,6 +275,8 @@ __global__ __launch_bounds__(1024) void k_gemv_kqt(const KqmParams p)
     const uint32_t a_off = g * 64 + (ra & 3) * 16;
 
     float acc = 0.f;
+    float best_v = -INFINITY;
+    uint32_t best_i = 0xFFFFFFFFu;
     uint32_t cst = 0, par = 0;
     auto consume = [&](Regs &buf) {
         const uint32_t ui = cst / (R * BPW), tt = (cst / BPW) % R, bi = cst % BPW;
@@ -326,11 +332,9 @@ __global__ __launch_bounds__(1024) void k_gemv_kqt(const KqmParams p)
                             sp[w & 3] += w < nw ? v : 0.f;
                         }
                         float s = (sp[0] + sp[1]) + (sp[2] + sp[3]);
-                        s += __shfl_xor(s, 16);
-                        s += __shfl_xor(s, 32);
-                        af[t2] = s;
+                        af[t2] = rows4_sum(s);
                     }
-                    kqm_epilogue<MODE>(p, uq, lane, af[0], af[R - 1], pre);
+                    kqm_epilogue<MODE>(p, uq, lane, af[0], af[R - 1], pre, best_v, best_i);
                 }
                 par ^= 1;
             }
@@ -361,6 +365,10 @@ __global__ __launch_bounds__(1024) void k_gemv_kqt(const KqmParams p)
         } else if (rem == 1) {
             consume(buf[0]);
         }
+    }
+    if constexpr (MODE == GEMV_PLAIN) {
+        // SamplingUtils.ArgMax over the outputs in the same launch (block-uniform: a kernel argument); its 48 LDS words sit behind `scal`
+        if (p.am.ticket != nullptr) argmax_fused_tail(best_v, best_i, p.am, reinterpret_cast<uint32_t *>(scal + 32));
     }
 }
 
@@ -629,6 +637,13 @@ hipError_t launch_gemv_kqm(const GemvArgs &a, hipStream_t s)
     p.rope_cs = a.rope_cs; p.rope_dims = a.rope_dims; p.D = a.D ? a.D : 2; p.pos = a.pos_dev;
     p.kv_f16 = a.kv_type == NFAI_F16;
     p.seg6 = a.seg6_mask;
+    if (a.argmax_part) {
+        if (a.mode != GEMV_PLAIN || !a.argmax_out) return hipErrorInvalidValue;
+        p.am.part_v = static_cast<float *>(a.argmax_part);
+        p.am.part_i = reinterpret_cast<uint32_t *>(p.am.part_v + ARGMAX_FUSED_MAX_BLOCKS);
+        p.am.ticket = p.am.part_i + ARGMAX_FUSED_MAX_BLOCKS;
+        p.am.out_idx = a.argmax_out; p.am.pos_inc = a.argmax_pos_inc; p.am.ring = a.argmax_ring; p.am.ring_len = a.argmax_ring_len;
+    }
     static const int env_bpw = getenv("NFAI_KQM_BPW") ? atoi(getenv("NFAI_KQM_BPW")) : 0;  // sweep knob: super-blocks per wave
     int bpw = p.NB <= 16 ? 1 : (p.NB <= 32 ? 2 : (p.NB <= 64 ? 4 : 8));  // K <= 32768 (Llama-70B: ffn length 28672)
     if ((env_bpw == 2 || env_bpw == 4) && env_bpw > bpw && p.NB % env_bpw == 0) bpw = env_bpw;
@@ -636,12 +651,13 @@ hipError_t launch_gemv_kqm(const GemvArgs &a, hipStream_t s)
     static const int env_bpc = getenv("NFAI_KQM_BPC") ? atoi(getenv("NFAI_KQM_BPC")) : 1;  // sweep knobs
     static const int env_ub = getenv("NFAI_KQM_UB") ? atoi(getenv("NFAI_KQM_UB")) : 4;
     const uint32_t grid = min(p.NU, a.n_cu * (uint32_t)max(1, min(env_bpc, 8)));
+    if (a.argmax_part && grid > ARGMAX_FUSED_MAX_BLOCKS) return hipErrorInvalidValue;
     const uint32_t upb = (p.NU + grid - 1) / grid;
     p.UB = min((uint32_t)max(1, min(env_ub, 8)), min(upb, nw));
     const int R = a.mode == GEMV_GATEUP ? 2 : 1;
     const size_t nlay = a.w_type == NFAI_KQ_MIXED ? 2 : 1;  // fragment layouts staged
     auto lds_bytes = [&](uint32_t ub) {
-        return nlay * ((size_t)nw * bpw * 1024 + (size_t)nw * bpw * 64) + (size_t)nw * bpw * 4 + (size_t)2 * ub * R * nw * 256 + 128;
+        return nlay * ((size_t)nw * bpw * 1024 + (size_t)nw * bpw * 64) + (size_t)nw * bpw * 4 + (size_t)2 * ub * R * nw * 256 + 128 + 192;  // + 48 words of the fused ArgMax
     };
     while (p.UB > 1 && lds_bytes(p.UB) > 160 * 1024) p.UB--;  // very long K: fewer units per reduction round
     const size_t lds = lds_bytes(p.UB);

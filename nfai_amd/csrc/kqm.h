@@ -30,6 +30,7 @@ struct KqmParams {
     uint32_t rope_dims, D;
     const uint32_t *pos;
     int kv_f16;
+    ArgmaxFused am;            // GEMV_PLAIN: first index of the largest output, taken in this launch (am.ticket == nullptr: off)
 };
 
 struct Q4T { u32x4 q0, q1, hdr; };

@@ -492,10 +492,18 @@ int enqueue_token(Model *m, bool with_head)
         GemvArgs a = gemv_base(m, head, x_final, d.E);
         a.gamma = static_cast<const float *>(m->output_norm.ptr);
         a.y = m->logits;
+        // SamplingUtils.ArgMax + the end-of-token bookkeeping ride on the lm_head launch (LlamaModel.cs:125-130 in one launch): the
+        // streaming GEMV kernels take it; the fallback kernel for K-quant tensors whose rows are not a multiple of 16 does not
+        const bool am_fused = head.type == NFAI_F16 || head.type == NFAI_F32 || head.type == NFAI_Q4_K_T16 || head.type == NFAI_Q6_K_T16;
+        if (am_fused) {
+            a.argmax_part = static_cast<char *>(m->d_argmax_part) + 4096;
+            a.argmax_out = m->d_tok; a.argmax_pos_inc = m->d_pos; a.argmax_ring = m->d_ring; a.argmax_ring_len = RING_LEN;
+        }
         S_TRY(sch.submit(op_gemv(KC_LMHEAD, a)));
-        S_TRY(sch.submit(op_fn(KC_OTHER, [m](hipStream_t st) {
-            return launch_argmax(m->logits, m->d.V, m->d_tok, m->d_argmax_part, m->d_pos, m->d_ring, RING_LEN, st);
-        })));
+        if (!am_fused)
+            S_TRY(sch.submit(op_fn(KC_OTHER, [m](hipStream_t st) {
+                return launch_argmax(m->logits, m->d.V, m->d_tok, m->d_argmax_part, m->d_pos, m->d_ring, RING_LEN, st);
+            })));
     } else {
         S_TRY(sch.submit(op_fn(KC_OTHER, [m](hipStream_t st) { return launch_pos_advance(m->d_pos, st); })));
     }
@@ -660,7 +668,7 @@ NFAI_API int32_t nfai_hip_llama_create(nfai_ctx_t ch, const nfai_llama_desc *des
     DALLOC(m->d_ring, RING_LEN * 4);
     DALLOC(m->d_freqs, (d.D / 2 + 8) * 4);
     DALLOC(m->d_ropecs, (d.D + 16) * 4);
-    DALLOC(m->d_argmax_part, 4096);
+    DALLOC(m->d_argmax_part, 4096 + argmax_fused_bytes());  // k_argmax's partials | the fused lm_head + ArgMax launch's
     DALLOC(m->d_epoch, 256);
     DALLOC(m->d_engerr, 256);
     if (m->engine) DALLOC(m->d_gran, (size_t)m->layers.size() * (2 * (size_t)d.E + d.F) * 8);
@@ -1381,7 +1389,9 @@ NFAI_API int32_t nfai_hip_llama_profile_kernel(nfai_model_t h, uint32_t token, i
     for (uint32_t r = 0; r < reps; r++)
         for (const Op &op : m->prof_ops) {
             if (bump && bump_launch() != hipSuccess) return fail(NFAI_ERR_HIP, "profile_kernel: tag launch failed");
-            hipError_t e = op.kind == 0 ? launch_gemv(op.g, s) : (op.kind == 1 ? launch_attn_decode(op.a, s) : op.f(s));
+            GemvArgs g = op.g;
+            g.argmax_part = nullptr;  // a replayed lm_head must not advance the position again (the GEMV itself is idempotent)
+            hipError_t e = op.kind == 0 ? launch_gemv(g, s) : (op.kind == 1 ? launch_attn_decode(op.a, s) : op.f(s));
             if (e != hipSuccess) return fail(NFAI_ERR_HIP, "profile_kernel: replay launch failed: %s", hipGetErrorString(e));
         }
     HIP_TRY(hipEventRecord(m->prof_rep_ev[1], s));

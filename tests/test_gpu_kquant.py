@@ -77,6 +77,35 @@ def test_embed_kquant(mgr, qt):
 
 
 @pytest.mark.parametrize("qt", [Q4_K, Q6_K])
+@pytest.mark.parametrize("V,E", [(128256, 768), (4000, 3072), (48, 256)])
+def test_lmhead_argmax_kquant(mgr, qt, V, E):
+    """RMSNorm + K-quant lm_head + ArgMax in one launch: logits against the dequantised GEMV, index = first maximum of the
+    launch's own logits; equal maxima (copied rows) in different workgroups resolve to the lowest index."""
+    from nfai_amd._lib import call
+    from nfai_amd.hip import ShaderProperty
+    r = rng(V + E + qt)
+    rows = min(V, 2048)
+    W = np.tile((0.02 * r.standard_normal((rows, E))).astype(np.float32), ((V + rows - 1) // rows, 1))[:V].copy()
+    W *= (1 + 0.01 * r.standard_normal((V, 1))).astype(np.float32)
+    x = r.standard_normal(E).astype(np.float32)
+    g = (1 + 0.1 * r.standard_normal(E)).astype(np.float32)
+    xn = orc.rmsnorm(x, g, 1e-5)
+    dup = (V - 1, 35, V // 2 + 1)
+    for j in dup:
+        W[j] = np.sign(xn) * 0.06
+    raw, Wd = quantize(W, qt)
+    tab = mgr.UploadWeight(qt, raw, V, E)
+    px, pg, pl, pi = ShaderProperty(mgr, E), ShaderProperty(mgr, E), ShaderProperty(mgr, V), ShaderProperty(mgr, 1, np.uint32)
+    px.SetValue(x); pg.SetValue(g)
+    for _ in range(2):
+        call("nfai_hip_lmhead_argmax", mgr.handle, tab.handle, qt, px.handle, pg.handle, 1e-5, pl.handle, pi.handle, V, E)
+        lg = pl.GetValue()
+        sl = slice(0, min(V, 2500))
+        assert (np.abs(lg[sl] - orc.gemv(Wd[sl], xn)) <= tol(Wd[sl], xn)).all()
+        assert int(pi.GetValue()[0]) == int(np.argmax(lg)) == min(dup)
+
+
+@pytest.mark.parametrize("qt", [Q4_K, Q6_K])
 @pytest.mark.parametrize("E,F", [(3072, 8192), (2048, 8192), (256, 512)])
 def test_gateup_and_residual_kquant(mgr, qt, E, F):
     from nfai_amd._lib import call

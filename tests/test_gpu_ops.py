@@ -222,6 +222,40 @@ def test_silu_mul_add_embed_argmax(mgr):
     assert int(pi.GetValue()[0]) == 3
 
 
+# ---- output norm + lm_head + ArgMax in one launch (LlamaModel.cs:123-125 + SamplingUtils.cs:43-57) -------------------------------
+@pytest.mark.parametrize("V,E,norm", [(128256, 256, True), (128256, 3072, True), (32000, 2048, False), (1000, 264, True), (17, 8, False)])
+def test_lmhead_argmax_one_launch(mgr, V, E, norm):
+    """logits as the plain GEMV gives them, and the FIRST index of the maximum (SamplingUtils.cs:55-56) also when equal maxima
+    come out of different workgroups: rows 77, V // 2 + 3 and V - 1 of the table are copies of one row with the largest output."""
+    from nfai_amd._lib import call
+    from nfai_amd.hip import ShaderProperty
+    r = rng(V + E)
+    rows = min(V, 4096)                                   # the oracle GEMV runs on a slice; the full table is tiled from it
+    base = (0.02 * r.standard_normal((rows, E))).astype(np.float16)
+    W = np.tile(base, ((V + rows - 1) // rows, 1))[:V].copy()
+    W += (1e-3 * r.standard_normal((V, 1))).astype(np.float16)   # rows differ again
+    x = r.standard_normal(E).astype(np.float32)
+    g = (1 + 0.1 * r.standard_normal(E)).astype(np.float32)
+    xn = orc.rmsnorm(x, g, 1e-5) if norm else x
+    if V >= 1000:
+        big = (np.sign(xn) * 0.05).astype(np.float16)     # a row whose output beats every other
+        for j in (V - 1, 77, V // 2 + 3):
+            W[j] = big
+    tab = mgr.UploadWeight(1, W, V, E)
+    px, pg, pl, pi = ShaderProperty(mgr, E), ShaderProperty(mgr, E), ShaderProperty(mgr, V), ShaderProperty(mgr, 1, np.uint32)
+    px.SetValue(x)
+    pg.SetValue(g)
+    for _ in range(3):  # the ticket re-arms
+        call("nfai_hip_lmhead_argmax", mgr.handle, tab.handle, 1, px.handle, pg.handle if norm else 0, 1e-5, pl.handle, pi.handle, V, E)
+        lg = pl.GetValue()
+        sl = slice(0, min(V, 3000))
+        ref = orc.gemv_f16w(W[sl], xn)
+        assert (np.abs(lg[sl] - ref) <= gemv_tol(W[sl].astype(np.float32), xn)).all()
+        assert int(pi.GetValue()[0]) == int(np.argmax(lg)) == orc.argmax(lg)      # exact on the launch's own logits
+        if V >= 1000:
+            assert int(pi.GetValue()[0]) == 77
+
+
 # ---- candidates of SamplingUtils.TopP on the device (SamplingUtils.cs:5-13) --------------------------------------------------
 @pytest.mark.parametrize("n,k,temperature,seed", [(128256, 40, 0.5, 1), (128256, 64, 1.0, 2), (32000, 40, 0.5, 3), (1000, 40, 0.5, 4),
                                                   (40, 40, 0.7, 5), (65, 1, 0.5, 6), (300000, 40, 0.5, 7)])

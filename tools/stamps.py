@@ -147,6 +147,12 @@ def main():
                 d["ticket"].extend(t[:, 6] - t[:, 5])
                 d["merge"].extend(mg[:, 7] - mg[:, 6])
             else:                     # granule hand-off: every block merges its share of the outputs after stamp 4
+                # the launch ends with its SLOWEST wave: per launch, the latest time any wave reaches each stamp (since the launch's first)
+                for kk, nm in ((1, "requested"), (2, "scores"), (3, "softmax"), (4, "published"), (5, "all_seen"), (7, "stored")):
+                    col_ = t[:, kk][t[:, kk] > 0]
+                    if col_.size:
+                        d.setdefault("slowest_wave_" + nm, []).append(float(col_.max() - L["t0"]))
+                        d.setdefault("fastest_wave_" + nm, []).append(float(col_.min() - L["t0"]))
                 d.setdefault("own_slice_published", []).extend(t[:, 4] - L["t0"])
                 d.setdefault("all_granules_seen_after_own_publish", []).extend(mg[:, 5] - mg[:, 4])
                 d.setdefault("merge_and_store", []).extend(mg[:, 7] - mg[:, 5])
