@@ -4,8 +4,10 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <unordered_set>
+#include <vector>
 
 #include "common.h"
 
@@ -177,11 +179,13 @@ NFAI_API int32_t nfai_hip_ctx_destroy(nfai_ctx_t h)
     return NFAI_OK;
 }
 
+static int canary_check_all(Ctx *c);  // NFAI_HIP_DEBUG_CANARY (below, with nfai_hip_buf_alloc)
+
 NFAI_API int32_t nfai_hip_ctx_synchronize(nfai_ctx_t h)
 {
     CTX_OR_FAIL(c, h);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return NFAI_OK;
+    return canary_check_all(c);
 }
 
 NFAI_API int32_t nfai_hip_ctx_device_info(nfai_ctx_t h, nfai_device_info *info)
@@ -217,16 +221,69 @@ NFAI_API int32_t nfai_hip_timer_end(nfai_ctx_t h, float *ms)
 }
 
 // ---- buffers ---------------------------------------------------------------------------------
+// NFAI_HIP_DEBUG_CANARY=1 (read once): every buffer of nfai_hip_buf_alloc sits between two 256-byte guards filled with a
+// pattern; nfai_hip_buf_free and nfai_hip_ctx_synchronize verify them and fail with NFAI_ERR_HIP naming the buffer when a kernel
+// (or a copy through a wrapped alias) wrote outside its buffer.  The build's stand-in for the validation layer the reference
+// switches on unconditionally (NFAI.Vulkan/VulkanHelper.cs:14-17,126-131; robustBufferAccess is off there too, :206-219).
+namespace {
+constexpr uint64_t CANARY_BYTES = 256;
+constexpr int CANARY_BYTE = 0xC5;
+bool canary_on()
+{
+    static const bool on = getenv("NFAI_HIP_DEBUG_CANARY") && atoi(getenv("NFAI_HIP_DEBUG_CANARY")) != 0;
+    return on;
+}
+std::mutex g_canary_mu;
+std::vector<Buf *> g_canary_bufs;
+
+// guards of one buffer; stream must be idle.  0 = intact.
+int canary_check(Buf *b, const char *when)
+{
+    if (!b->guard_base) return NFAI_OK;
+    const uint64_t padded = (b->bytes + 255) & ~255ull;
+    unsigned char host[2 * CANARY_BYTES];
+    HIP_TRY(hipMemcpy(host, b->guard_base, CANARY_BYTES, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(host + CANARY_BYTES, static_cast<char *>(b->ptr) + padded, CANARY_BYTES, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < 2 * CANARY_BYTES; i++)
+        if (host[i] != CANARY_BYTE)
+            return fail(NFAI_ERR_HIP, "%s: a write outside buffer %p (%llu bytes) was detected: guard byte %llu %s the buffer is 0x%02x (NFAI_HIP_DEBUG_CANARY)",
+                        when, b->ptr, (unsigned long long)b->bytes, (unsigned long long)(i % CANARY_BYTES), i < CANARY_BYTES ? "before" : "after", host[i]);
+    return NFAI_OK;
+}
+}  // namespace
+
+static int canary_check_all(Ctx *c)
+{
+    if (!canary_on()) return NFAI_OK;
+    std::lock_guard<std::mutex> lk(g_canary_mu);
+    for (Buf *b : g_canary_bufs)
+        if (b->ctx == c) {
+            int rc = canary_check(b, "ctx_synchronize");
+            if (rc) return rc;
+        }
+    return NFAI_OK;
+}
+
 NFAI_API int32_t nfai_hip_buf_alloc(nfai_ctx_t h, uint64_t bytes, nfai_buf_t *out)
 {
     CTX_OR_FAIL(c, h);
     if (!out || bytes == 0) return fail(NFAI_ERR_INVALID, "buf_alloc: out null or zero bytes");
     Buf *b = new Buf();
     const uint64_t padded = (bytes + 255) & ~255ull;  // 16-byte vector accesses may touch the tail
-    hipError_t e = hipMalloc(&b->ptr, padded);
+    const uint64_t guard = canary_on() ? CANARY_BYTES : 0;
+    void *base = nullptr;
+    hipError_t e = hipMalloc(&base, padded + 2 * guard);
     if (e != hipSuccess) {
         delete b;
         return fail(NFAI_ERR_OOM, "buf_alloc: hipMalloc(%llu) failed: %s", (unsigned long long)padded, hipGetErrorString(e));
+    }
+    b->ptr = static_cast<char *>(base) + guard;
+    if (guard) {
+        b->guard_base = base;
+        HIP_TRY(hipMemsetAsync(base, CANARY_BYTE, guard, c->stream));
+        HIP_TRY(hipMemsetAsync(static_cast<char *>(b->ptr) + padded, CANARY_BYTE, guard, c->stream));
+        std::lock_guard<std::mutex> lk(g_canary_mu);
+        g_canary_bufs.push_back(b);
     }
     HIP_TRY(hipMemsetAsync(b->ptr, 0, padded, c->stream));
     b->bytes = bytes;
@@ -256,14 +313,20 @@ NFAI_API int32_t nfai_hip_buf_free(nfai_ctx_t h, nfai_buf_t bh)
 {
     CTX_OR_FAIL(c, h);
     BUF_OR_FAIL(b, bh);
+    int canary_rc = NFAI_OK;
     if (b->owned) {
         HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipFree(b->ptr));
+        if (b->guard_base) {
+            canary_rc = canary_check(b, "buf_free");
+            std::lock_guard<std::mutex> lk(g_canary_mu);
+            g_canary_bufs.erase(std::remove(g_canary_bufs.begin(), g_canary_bufs.end(), b), g_canary_bufs.end());
+        }
+        HIP_TRY(hipFree(b->guard_base ? b->guard_base : b->ptr));
     }
     b->magic = 0;
     handle_unregister(b);
     delete b;
-    return NFAI_OK;
+    return canary_rc;
 }
 
 NFAI_API int32_t nfai_hip_buf_upload(nfai_ctx_t h, nfai_buf_t bh, uint64_t off, const void *host, uint64_t bytes)

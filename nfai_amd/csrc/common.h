@@ -64,6 +64,7 @@ struct Buf {
     uint64_t bytes = 0;
     bool owned = true;
     Ctx *ctx = nullptr;
+    void *guard_base = nullptr;  // NFAI_HIP_DEBUG_CANARY: start of the allocation (256-byte guard | buffer | 256-byte guard)
 };
 
 Ctx *ctx_of(nfai_ctx_t h);
@@ -185,6 +186,7 @@ struct AttnArgs {
     const uint32_t *epoch = nullptr;
     uint32_t tag_mul = 1, tag_add = 0;
     uint32_t *err = nullptr;
+    uint32_t debug_withhold = 0;  // test hook: slice (value - 1) of kv head 0 publishes nothing, so the others' bounded waits give up
 };
 constexpr uint32_t ATTN_NSPLIT_MAX = 32;
 size_t attn_partials_bytes(uint32_t H, uint32_t Hkv, uint32_t D, bool granules = false);  // granules: the {value, tag} form (AttnArgs::epoch set)

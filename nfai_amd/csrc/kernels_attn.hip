@@ -59,6 +59,7 @@ struct AttnParams {
     uint32_t E, HD, nbw;     // Wo rows, row length, workgroups that share the rows
     uint32_t wo_lds_off;     // byte offset of the Wo waves' LDS region (after the attention waves')
     uint32_t wo_delay;       // x 64 clocks between launch start and the Wo waves' weight requests (workgroups that run a slice)
+    uint32_t withhold;       // test hook (AttnArgs::debug_withhold)
     NFAI_STAMP_PARAM
 };
 
@@ -375,7 +376,7 @@ __device__ __forceinline__ void attn_body(const AttnParams &p, const uint32_t kv
                         publish(p.att_gran + (uint64_t)(kvh * G + g) * D + d, tag, s0 * inv);
                         publish(p.att_gran + (uint64_t)(kvh * G + g) * D + d + 1, tag, s1 * inv);
                     }
-                } else {
+                } else if (!(p.withhold && split + 1 == p.withhold && kvh == 0)) {  // (test hook: a slice that never publishes)
                     uint64_t *row = gbase + ((uint64_t)split * G + g) * ROW;
                     publish(row + d, tag, s0);
                     publish(row + d + 1, tag, s1);
@@ -702,6 +703,38 @@ size_t attn_partials_bytes(uint32_t H, uint32_t Hkv, uint32_t D, bool granules)
 
 size_t attn_wo_extra_bytes(uint32_t H, uint32_t D) { return (size_t)H * D * sizeof(uint64_t) + 256; }
 
+// The slices' workgroups of the granule form wait for each other, so ALL of them must be resident at once: what the occupancy
+// query says a CU holds of this very kernel (registers, LDS, waves) times the CUs must cover the grid; otherwise the ticket form,
+// which never waits, is launched.  (The query knows nothing of other processes on the device: for that case every wait is bounded
+// and llama.hip re-runs the token on the ticket form.)
+template <typename K>
+static bool grid_resident(K kernel, uint32_t threads, size_t lds, uint32_t blocks, uint32_t n_cu)
+{
+    static size_t memo_lds = ~(size_t)0;  // per kernel instantiation: the last answer (the LDS size only changes with the KV capacity)
+    static uint32_t memo_threads = 0;
+    static int memo_per_cu = 0;
+    if (memo_lds != lds || memo_threads != threads) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)threads, lds) != hipSuccess) { (void)hipGetLastError(); return false; }
+        memo_per_cu = per_cu; memo_lds = lds; memo_threads = threads;
+    }
+    return memo_per_cu > 0 && (uint64_t)memo_per_cu * n_cu >= blocks;
+}
+
+template <int LPP, bool F16, bool ONLINE, bool POLL>
+static bool resident_gp(uint32_t G, dim3 grid, size_t lds, uint32_t n_cu)
+{
+    const uint32_t blocks = grid.x * grid.y;
+    switch (G) {
+        case 1: return grid_resident(k_attn_decode<LPP, 1, F16, ONLINE, POLL>, ATTN_BLOCK, lds, blocks, n_cu);
+        case 2: return grid_resident(k_attn_decode<LPP, 2, F16, ONLINE, POLL>, ATTN_BLOCK, lds, blocks, n_cu);
+        case 3: return grid_resident(k_attn_decode<LPP, 3, F16, ONLINE, POLL>, ATTN_BLOCK, lds, blocks, n_cu);
+        case 4: return grid_resident(k_attn_decode<LPP, 4, F16, ONLINE, POLL>, ATTN_BLOCK, lds, blocks, n_cu);
+        case 8: return grid_resident(k_attn_decode<LPP, 8, F16, ONLINE, POLL>, ATTN_BLOCK, lds, blocks, n_cu);
+    }
+    return false;
+}
+
 template <int LPP, bool F16, bool ONLINE, bool POLL>
 static hipError_t launch_gp(const AttnParams &p, uint32_t G, dim3 grid, size_t lds, hipStream_t s)
 {
@@ -717,9 +750,12 @@ static hipError_t launch_gp(const AttnParams &p, uint32_t G, dim3 grid, size_t l
 }
 
 template <int LPP, bool F16, bool ONLINE>
-static hipError_t launch_g(const AttnParams &p, uint32_t G, dim3 grid, size_t lds, hipStream_t s)
+static hipError_t launch_g(const AttnParams &p, uint32_t G, dim3 grid, size_t lds, hipStream_t s, uint32_t n_cu)
 {
-    return p.epoch ? launch_gp<LPP, F16, ONLINE, true>(p, G, grid, lds, s) : launch_gp<LPP, F16, ONLINE, false>(p, G, grid, lds, s);
+    if (p.epoch && resident_gp<LPP, F16, ONLINE, true>(G, grid, lds, n_cu)) return launch_gp<LPP, F16, ONLINE, true>(p, G, grid, lds, s);
+    AttnParams q = p;
+    q.epoch = nullptr;
+    return launch_gp<LPP, F16, ONLINE, false>(q, G, grid, lds, s);
 }
 
 static hipError_t fill_params(const AttnArgs &a, AttnParams &p, dim3 &grid, size_t &lds, bool &online)
@@ -737,10 +773,10 @@ static hipError_t fill_params(const AttnArgs &a, AttnParams &p, dim3 &grid, size
     p.partials = a.partials + 64;
     p.H = a.H; p.Hkv = a.Hkv; p.D = a.D; p.pos = a.pos_dev;
     static const int env_poll = getenv("NFAI_ATTN_POLL") ? atoi(getenv("NFAI_ATTN_POLL")) : 1;  // 0: ticket hand-off everywhere (A/B runs)
-    // granule hand-off: the slices' workgroups poll each other, so all Hkv x slices of them must be resident at once (four
-    // 256-thread workgroups fit a CU); on a smaller device (a partition) the ticket form, which never waits, is used
-    p.epoch = (env_poll && (uint64_t)a.n_cu * 4 >= (uint64_t)a.Hkv * ATTN_NSPLIT_MAX) ? a.epoch : nullptr;
-    p.tag_mul = a.tag_mul; p.tag_add = a.tag_add; p.err = a.err;
+    // granule hand-off: the slices' workgroups poll each other, so all Hkv x slices of them must be resident at once; where the
+    // occupancy query says they are not (a partition with few CUs) the ticket form, which never waits, is used
+    p.epoch = env_poll ? a.epoch : nullptr;  // (launch_g checks that the whole grid can be resident)
+    p.tag_mul = a.tag_mul; p.tag_add = a.tag_add; p.err = a.err; p.withhold = a.debug_withhold;
     static const int env_mc = getenv("NFAI_ATTN_MIN_CHUNK") ? atoi(getenv("NFAI_ATTN_MIN_CHUNK")) : 0;
     static const int env_ms = getenv("NFAI_ATTN_MAX_SPLIT") ? atoi(getenv("NFAI_ATTN_MAX_SPLIT")) : 0;
     p.min_chunk = env_mc >= 4 ? (uint32_t)env_mc : ATTN_MIN_CHUNK;
@@ -777,11 +813,11 @@ hipError_t launch_attn_decode(const AttnArgs &a, hipStream_t s)
     const bool f16 = a.kv_type == NFAI_F16;
     NFAI_STAMP_SET(p, "attn_decode", a.Hkv * p.max_split, ATTN_BLOCK);
     if (online) {
-        if (a.D == 64) return f16 ? launch_g<16, true, true>(p, G, grid, lds, s) : launch_g<16, false, true>(p, G, grid, lds, s);
-        return f16 ? launch_g<32, true, true>(p, G, grid, lds, s) : launch_g<32, false, true>(p, G, grid, lds, s);
+        if (a.D == 64) return f16 ? launch_g<16, true, true>(p, G, grid, lds, s, a.n_cu) : launch_g<16, false, true>(p, G, grid, lds, s, a.n_cu);
+        return f16 ? launch_g<32, true, true>(p, G, grid, lds, s, a.n_cu) : launch_g<32, false, true>(p, G, grid, lds, s, a.n_cu);
     }
-    if (a.D == 64) return f16 ? launch_g<16, true, false>(p, G, grid, lds, s) : launch_g<16, false, false>(p, G, grid, lds, s);
-    return f16 ? launch_g<32, true, false>(p, G, grid, lds, s) : launch_g<32, false, false>(p, G, grid, lds, s);
+    if (a.D == 64) return f16 ? launch_g<16, true, false>(p, G, grid, lds, s, a.n_cu) : launch_g<16, false, false>(p, G, grid, lds, s, a.n_cu);
+    return f16 ? launch_g<32, true, false>(p, G, grid, lds, s, a.n_cu) : launch_g<32, false, false>(p, G, grid, lds, s, a.n_cu);
 }
 
 // ---- attention + Wo: the shapes it is built for (anything else takes the two launches) -------------------------------------
@@ -799,8 +835,6 @@ static bool attn_wo_plan(const AttnArgs &a, const GemvArgs &g, uint32_t &nbw, At
     static const int env_poll = getenv("NFAI_ATTN_POLL") ? atoi(getenv("NFAI_ATTN_POLL")) : 1;
     static const int env_online = getenv("NFAI_ATTN_ONLINE") ? atoi(getenv("NFAI_ATTN_ONLINE")) : -1;
     if (!env || !env_poll || env_online == 1 || !a.epoch || a.C > 2048) return false;
-    // the slices' workgroups wait for each other: all of them must be resident at once, and this launch holds one per CU
-    if (a.n_cu < a.Hkv * ATTN_NSPLIT_MAX) return false;
     if (g.mode != GEMV_RESIDUAL || g.gamma || !g.res || g.x != a.o) return false;
     if (a.Hkv == 0 || a.H % a.Hkv || (a.D != 64 && a.D != 128)) return false;
     const uint32_t HD = a.H * a.D, E = g.seg_rows[0];
@@ -819,11 +853,11 @@ static bool attn_wo_plan(const AttnArgs &a, const GemvArgs &g, uint32_t &nbw, At
     return false;
 }
 
-bool attn_wo_ok(const AttnArgs &a, const GemvArgs &g)
+template <int LPP, int G, int R, int U>
+static bool resident_aw(bool f16, uint32_t nblocks, size_t lds, uint32_t n_cu)
 {
-    uint32_t nbw;
-    AttnWoShape sh;
-    return attn_wo_plan(a, g, nbw, sh);
+    return f16 ? grid_resident(k_attn_wo<LPP, G, true, R, U>, ATTN_BLOCK + WO_WAVES * 64, lds, nblocks, n_cu)
+               : grid_resident(k_attn_wo<LPP, G, false, R, U>, ATTN_BLOCK + WO_WAVES * 64, lds, nblocks, n_cu);
 }
 
 template <int LPP, int G, int R, int U>
@@ -834,18 +868,15 @@ static hipError_t launch_aw(const AttnParams &p, bool f16, uint32_t nblocks, siz
     return hipGetLastError();
 }
 
-hipError_t launch_attn_wo(const AttnArgs &a, const GemvArgs &g, hipStream_t s)
+// shapes, workspace pointers, grid and LDS size of the fused launch; false: this pair of ops takes the two launches
+static bool attn_wo_prepare(const AttnArgs &a, const GemvArgs &g, AttnParams &p, AttnWoShape &sh, uint32_t &nblocks, size_t &lds)
 {
     uint32_t nbw;
-    AttnWoShape sh;
-    if (!attn_wo_plan(a, g, nbw, sh)) return hipErrorInvalidValue;
-    AttnParams p{};
+    if (!attn_wo_plan(a, g, nbw, sh)) return false;
     dim3 grid;
-    size_t lds = 0;
     bool online = false;
-    hipError_t e = fill_params(a, p, grid, lds, online);
-    if (e != hipSuccess) return e;
-    if (online || !p.epoch) return hipErrorInvalidValue;
+    lds = 0;
+    if (fill_params(a, p, grid, lds, online) != hipSuccess || online || !p.epoch) return false;
     const uint32_t HD = a.H * a.D;
     // the merged attention output as granules sits behind the slices' granules in the workspace
     p.att_gran = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(a.partials) + attn_partials_bytes(a.H, a.Hkv, a.D, true));
@@ -854,10 +885,34 @@ hipError_t launch_attn_wo(const AttnArgs &a, const GemvArgs &g, hipStream_t s)
     static const int env_delay = getenv("NFAI_ATTN_WO_DELAY") ? atoi(getenv("NFAI_ATTN_WO_DELAY")) : 54;  // x 64 clocks = 1.4 us
     p.wo_delay = env_delay >= 0 && env_delay < 4096 ? (uint32_t)env_delay : 54;
     p.wo_lds_off = (uint32_t)((lds + 15) & ~(size_t)15);
-    const bool f16 = a.kv_type == NFAI_F16;
-    uint32_t nblocks = a.Hkv * p.max_split > nbw ? a.Hkv * p.max_split : nbw;
+    nblocks = a.Hkv * p.max_split > nbw ? a.Hkv * p.max_split : nbw;
     lds = p.wo_lds_off + ((size_t)HD + 16) * sizeof(float);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) return false;
+    // every workgroup of this launch waits for others: the whole grid must be resident at once (occupancy query of the kernel itself)
+    const bool f16 = a.kv_type == NFAI_F16;
+    if (sh.lpp == 32 && sh.G == 3) return resident_aw<32, 3, 3, 6>(f16, nblocks, lds, a.n_cu);
+    if (sh.lpp == 32 && sh.G == 4) return resident_aw<32, 4, 4, 8>(f16, nblocks, lds, a.n_cu);
+    if (sh.lpp == 16 && sh.G == 4) return resident_aw<16, 4, 2, 4>(f16, nblocks, lds, a.n_cu);
+    return resident_aw<32, 2, 1, 1>(f16, nblocks, lds, a.n_cu);
+}
+
+bool attn_wo_ok(const AttnArgs &a, const GemvArgs &g)
+{
+    AttnParams p{};
+    AttnWoShape sh;
+    uint32_t nblocks;
+    size_t lds;
+    return attn_wo_prepare(a, g, p, sh, nblocks, lds);
+}
+
+hipError_t launch_attn_wo(const AttnArgs &a, const GemvArgs &g, hipStream_t s)
+{
+    AttnParams p{};
+    AttnWoShape sh;
+    uint32_t nblocks;
+    size_t lds;
+    if (!attn_wo_prepare(a, g, p, sh, nblocks, lds)) return hipErrorInvalidValue;
+    const bool f16 = a.kv_type == NFAI_F16;
     NFAI_STAMP_SET(p, "attn_wo", nblocks, ATTN_BLOCK + WO_WAVES * 64);
     if (sh.lpp == 32 && sh.G == 3) return launch_aw<32, 3, 3, 6>(p, f16, nblocks, lds, s);
     if (sh.lpp == 32 && sh.G == 4) return launch_aw<32, 4, 4, 8>(p, f16, nblocks, lds, s);

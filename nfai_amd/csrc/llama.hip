@@ -49,6 +49,8 @@ struct Model {
     bool first_stage = false, last_stage = false;
     bool unfused = false, use_graph = true, kv_f16 = false;
     bool engine = false;             // requested: one engine launch per block where the tensors allow it
+    bool attn_ticket = false;        // a bounded wait of the granule hand-off gave up once: this model stays on the ticket form, which never waits
+    uint32_t dbg_withhold = 0;       // test hook (nfai_hip_debug_attn_withhold)
     uint64_t *d_gran = nullptr;      // engine hand-off granules: per block h (E) | act (F) | x (E)
     uint32_t *d_epoch = nullptr, *d_engerr = nullptr;
     void *d_engparams = nullptr;     // one parameter block per block's engine launch
@@ -354,7 +356,9 @@ AttnArgs attn_args(Model *m, Layer &L)
     a.pos_dev = m->d_pos; a.partials = m->d_attn_part;
     a.n_cu = (uint32_t)m->ctx->prop.multiProcessorCount;
     // slice hand-off by {value, tag} granules: tag = token epoch x blocks + block (never the tag of an earlier launch on this workspace)
-    a.epoch = m->d_epoch; a.tag_mul = (uint32_t)m->layers.size() + 1; a.tag_add = (uint32_t)(&L - m->layers.data()) + 1; a.err = m->d_engerr;
+    a.epoch = m->attn_ticket ? nullptr : m->d_epoch;
+    a.tag_mul = (uint32_t)m->layers.size() + 1; a.tag_add = (uint32_t)(&L - m->layers.data()) + 1; a.err = m->d_engerr;
+    a.debug_withhold = m->dbg_withhold;
     return a;
 }
 
@@ -898,6 +902,44 @@ NFAI_API int32_t nfai_hip_llama_finalize(nfai_model_t h)
     return NFAI_OK;
 }
 
+static void drop_graphs(Model *m)
+{
+    if (m->graph_exec) { hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    if (m->graph) { hipGraphDestroy(m->graph); m->graph = nullptr; }
+    if (m->stage_exec) { hipGraphExecDestroy(m->stage_exec); m->stage_exec = nullptr; }
+    if (m->stage_graph) { hipGraphDestroy(m->stage_graph); m->stage_graph = nullptr; }
+}
+
+// One token, blocking; the argmax and the sticky error word of the in-kernel waits land in m->h_pin[0..1].  The slices' workgroups
+// of the attention launch wait for each other (granule hand-off): when one of those bounded waits gives up (codes 0x1000-0x4000:
+// a workgroup was not resident, e.g. another process shares the device), the token's results are not valid — the model switches
+// to the ticket form, which never waits, for good, says so once on stderr, and the SAME token is run again from the same position.
+static int step_blocking(Model *m, uint32_t token)
+{
+    hipStream_t s = m->ctx->stream;
+    for (int attempt = 0;; attempt++) {
+        const uint32_t pos = m->pos_host;
+        int rc = set_token_async(m, token);
+        if (rc) return rc;
+        if ((rc = run_token(m))) return rc;
+        HIP_TRY(hipMemcpyAsync(m->h_pin, m->d_tok, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(m->h_pin + 1, m->d_engerr, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const uint32_t code = m->h_pin[1];
+        if (code == 0) return NFAI_OK;
+        if (attempt > 0 || m->attn_ticket || (code & ~0x7000u) != 0) return engine_failed(m, code);
+        fprintf(stderr, "nfai_hip: an attention launch gave up waiting for a KV slice's partial results (code 0x%x) at position %u — are all its "
+                        "workgroups resident?  Re-running the token on the ticket hand-off; this model keeps it from now on.\n", code, pos);
+        m->attn_ticket = true;
+        drop_graphs(m);  // captured with the granule form
+        HIP_TRY(hipMemsetAsync(m->d_engerr, 0, 4, s));
+        HIP_TRY(hipMemcpyAsync(m->d_pos, &pos, 4, hipMemcpyHostToDevice, s));  // the failed token may have advanced it
+        HIP_TRY(hipStreamSynchronize(s));
+        m->h_pin[1] = 0;
+        m->pos_host = pos;
+    }
+}
+
 #define NEED_FINAL(m) \
     if (!(m)->finalized) return fail(NFAI_ERR_STATE, "%s: call nfai_hip_llama_finalize first", __func__)
 
@@ -907,16 +949,14 @@ NFAI_API int32_t nfai_hip_llama_decode_step(nfai_model_t h, uint32_t token, floa
     NEED_FINAL(m);
     if (!(m->first_stage && m->last_stage)) return fail(NFAI_ERR_STATE, "decode_step: model is a pipeline stage; use nfai_hip_llama_stage_step");
     if (token >= m->d.V) return fail(NFAI_ERR_INVALID, "decode_step: token %u >= vocab %u", token, m->d.V);
-    int rc = set_token_async(m, token);
+    int rc = step_blocking(m, token);
     if (rc) return rc;
-    if ((rc = run_token(m))) return rc;
-    hipStream_t s = m->ctx->stream;
-    if (logits_host) HIP_TRY(hipMemcpyAsync(logits_host, m->logits, (size_t)m->d.V * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(m->h_pin, m->d_tok, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(m->h_pin + 1, m->d_engerr, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    if (m->h_pin[1]) return engine_failed(m, m->h_pin[1]);
     if (argmax) *argmax = m->h_pin[0];
+    if (logits_host) {
+        hipStream_t s = m->ctx->stream;
+        HIP_TRY(hipMemcpyAsync(logits_host, m->logits, (size_t)m->d.V * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
     return NFAI_OK;
 }
 
@@ -929,14 +969,9 @@ NFAI_API int32_t nfai_hip_llama_decode_topk(nfai_model_t h, uint32_t token, floa
     if (!(m->first_stage && m->last_stage)) return fail(NFAI_ERR_STATE, "decode_topk: model is a pipeline stage");
     if (token >= m->d.V) return fail(NFAI_ERR_INVALID, "decode_topk: token %u >= vocab %u", token, m->d.V);
     if (!m->d_topk) DALLOC(m->d_topk, topk_work_bytes(m->d.V));
-    int rc = set_token_async(m, token);
+    int rc = step_blocking(m, token);
     if (rc) return rc;
-    if ((rc = run_token(m))) return rc;
-    HIP_TRY(hipMemcpyAsync(m->h_pin + 1, m->d_engerr, 4, hipMemcpyDeviceToHost, m->ctx->stream));
-    rc = topk_run(m->ctx, m->logits, m->d.V, temperature, k, m->d_topk, ids_out, probs_out);  // synchronises
-    if (rc) return rc;
-    if (m->h_pin[1]) return engine_failed(m, m->h_pin[1]);
-    return NFAI_OK;
+    return topk_run(m->ctx, m->logits, m->d.V, temperature, k, m->d_topk, ids_out, probs_out);
 }
 
 NFAI_API int32_t nfai_hip_llama_set_token(nfai_model_t h, uint32_t token)
@@ -1436,5 +1471,16 @@ NFAI_API int32_t nfai_hip_llama_profile_step(nfai_model_t h, uint32_t token, flo
         ms_by_class[m->ev_class[i]] += ms;
         launches_by_class[m->ev_class[i]]++;
     }
+    return NFAI_OK;
+}
+
+// Test hook (not in nfai_hip.h): slice `slice_plus_1 - 1` of kv head 0 of every attention launch publishes nothing, so the bounded
+// waits of the granule hand-off give up and the fall-back to the ticket form can be exercised (tests/test_gpu_model.py).  0: off.
+NFAI_API int32_t nfai_hip_debug_attn_withhold(nfai_model_t h, uint32_t slice_plus_1)
+{
+    MODEL_OR_FAIL(m, h);
+    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    m->dbg_withhold = slice_plus_1;
+    drop_graphs(m);
     return NFAI_OK;
 }

@@ -208,3 +208,52 @@ def test_c_driver_runs_a_model_through_the_c_abi(tmp_path):
     r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().endswith("ok"), r.stdout
+
+
+@pytest.mark.gpu
+def test_canary_padded_debug_buffers_in_a_child_process():
+    """NFAI_HIP_DEBUG_CANARY=1 (read once per process): buffers sit between two guards.  A clean run of real kernels (GEMV with a
+    ragged row count, attention, argmax, top-k) leaves them intact; a write past the end of a buffer — made here through a wrapped
+    alias that is 64 bytes too long — is reported by the next synchronize and by the free, naming the buffer."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes as C, numpy as np, sys
+sys.path.insert(0, %r)
+from nfai_amd import _lib
+from nfai_amd._lib import call, NfaiHipError
+from nfai_amd.hip import HipBufferManager, ShaderProperty
+from nfai_amd.shaders import MatrixMultiplyShader
+mgr = HipBufferManager(0)
+r = np.random.default_rng(3)
+W = (0.02 * r.standard_normal((130, 1000))).astype(np.float16)
+op = MatrixMultiplyShader(mgr, 1, 1000, 130, W)
+op.GetInputProperty().SetValue(r.standard_normal(1000).astype(np.float32))
+op.Compute()
+y = op.GetOutputs()
+v = r.standard_normal(5000).astype(np.float32)
+pv, pi = ShaderProperty(mgr, v.size), ShaderProperty(mgr, 1, np.uint32)
+pv.SetValue(v)
+call("nfai_hip_argmax", mgr.handle, pv.handle, v.size, pi.handle)
+ids, probs = np.empty(40, np.uint32), np.empty(40, np.float32)
+call("nfai_hip_topk", mgr.handle, pv.handle, v.size, 0.5, 40, ids.ctypes.data_as(C.POINTER(C.c_uint32)), probs.ctypes.data_as(C.POINTER(C.c_float)))
+call("nfai_hip_ctx_synchronize", mgr.handle)            # every guard intact after real kernels
+assert int(pi.GetValue()[0]) == int(np.argmax(v)) and ids[0] == np.argmax(v)
+victim = ShaderProperty(mgr, 64)                         # 256 bytes: the allocation's padded end is the buffer's end
+ptr, nbytes = C.c_void_p(), C.c_uint64()
+call("nfai_hip_buf_info", mgr.handle, victim.buffer.handle, C.byref(ptr), C.byref(nbytes))
+alias = _lib.H()
+call("nfai_hip_buf_wrap", mgr.handle, ptr, nbytes.value + 64, C.byref(alias))
+junk = np.full(nbytes.value + 64, 7, np.uint8)
+call("nfai_hip_buf_upload", mgr.handle, alias, 0, junk.ctypes.data_as(C.c_void_p), junk.size)   # 64 bytes past the end
+try:
+    call("nfai_hip_ctx_synchronize", mgr.handle)
+    print("MISSED")
+except NfaiHipError as e:
+    print("CAUGHT", e)
+""" % ROOT
+    env = {**os.environ, "NFAI_HIP_DEBUG_CANARY": "1"}
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "CAUGHT" in r.stdout and "write outside buffer" in r.stdout and "after the buffer" in r.stdout, r.stdout
+

@@ -261,6 +261,41 @@ def test_bytes_per_token_accounting(mgr):
     m.Dispose()
 
 
+@pytest.mark.parametrize("dims", [synth.TINY, synth.TINY_D128], ids=lambda d: d.name)
+def test_attention_handoff_failure_falls_back_to_the_ticket_form(mgr, dims, capfd):
+    """The slices' workgroups of the attention launch wait for each other (bounded).  A test hook makes one slice publish
+    nothing: the waits give up, the error word is set — and the step must re-run the token on the ticket hand-off, say so once,
+    return the oracle's logits, and keep working (ticket form) afterwards.  One provoked failure, not a loop."""
+    import ctypes as C
+    from nfai_amd import _lib
+    from nfai_amd.llama_model import LlamaModel
+    w = synth.make_weights(dims, seed=71, std=0.06)
+    m = LlamaModel(mgr, synth.make_metadata(dims), w, 96)
+    ref = orc.OracleLlama(odesc(dims, 96), w)
+    toks = synth.make_tokens(dims, 44, seed=5)
+    for t in toks[:40]:                                  # 40 positions: two slices per kv head from here on
+        lg, _ = m.Step(int(t))
+        lr = ref.step(int(t))
+    tol = 2e-3 * max(1.0, float(np.abs(lr).max()))
+    assert np.abs(lg - lr).max() <= tol
+    lib = _lib.load()
+    lib.nfai_hip_debug_attn_withhold.argtypes = [_lib.H, C.c_uint32]
+    lib.nfai_hip_debug_attn_withhold.restype = C.c_int32
+    assert lib.nfai_hip_debug_attn_withhold(m.handle, 2) == 0      # slice 1 of kv head 0 stays silent
+    capfd.readouterr()
+    lg, am = m.Step(int(toks[40]))                       # fails inside, falls back, re-runs position 40
+    lr = ref.step(int(toks[40]))
+    err = capfd.readouterr().err
+    assert "ticket hand-off" in err and "position 40" in err
+    assert np.abs(lg - lr).max() <= tol and am == orc.argmax(lg) and m.Pos == 41
+    for t in toks[41:]:                                  # the model stays on the ticket form (the hook only gags the granule form)
+        lg, _ = m.Step(int(t))
+        lr = ref.step(int(t))
+        assert np.abs(lg - lr).max() <= tol
+    assert "ticket hand-off" not in capfd.readouterr().err   # logged once
+    m.Dispose()
+
+
 def test_topk_sampling_path(mgr):
     """The reference's DEFAULT sampler (LlamaModel.cs:128-130,165: SamplingUtils.TopP) with its first half on the device:
     after every step nfai_hip_llama_decode_topk must return the candidates TopP forms from the oracle's logits, and the token
@@ -517,11 +552,15 @@ def test_full_size_parity_through_bench(quant):
                        env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
-    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["max_abs_logit_diff_vs_gpu_token0"] <= 2e-3   # logits are O(1) here
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["max_abs_logit_diff_vs_gpu_token0"] <= 2e-3   # logits are O(1) here
+    # positions 0..3 through all 28 blocks (multi-position attention at full size), greedy tokens identical at every step
+    assert len(cb["max_abs_logit_diff_vs_gpu_by_position"]) == 4 and max(cb["max_abs_logit_diff_vs_gpu_by_position"]) <= 2e-3
+    assert all(cb["greedy_tokens_equal_by_position"]) and cb["value_1core"] > 0
     chk = d["prefill"]["check"]
     assert chk["same_argmax"] and chk["max_abs_logit_diff"] <= chk["tolerance"]
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and 0.3 < rf["frac"] < 1.0 and rf["traffic"] and 0.95 < rf["traffic"] / rf["bytes_per_launch"] < 1.1
+    assert rf["bound"] == "hbm" and 0.3 < rf["frac"] < 1.0   # (`traffic` is a committed offline PMC figure, labelled so: nothing to assert on)
     assert d["n_gpus"] == 1 and d["steps"] == 16 and d["value"] > 100
 
 

@@ -1,6 +1,8 @@
 """The CPU oracle (oracle/nfai_oracle.c) against (a) hand-computed known answers and (b) the
 independent fp64 NumPy evaluation (oracle/np_oracle.py).  The reference has no golden vectors for
 this path (parity unpinned); these tests pin the oracle to the op definitions."""
+import os
+
 import numpy as np
 import pytest
 
@@ -196,3 +198,16 @@ def test_topp_restatement(n, seed):
     flat = np.zeros(n, np.float32)
     tok, ids, probs, kept = orc.topp(flat, 1.0, 0.95, k, 0.5)
     assert kept == k and list(ids) == list(range(k)) and tok == _topp_fp64(flat, 1.0, 0.95, k, 0.5)[0] and tok in (19, 20)
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="sanitizer builds run on the CPU container only (never on the GPU box)")
+def test_oracle_under_address_and_ub_sanitizers():
+    """oracle/san_driver.c drives every exported function of the oracle at ragged sizes on exactly-sized heap buffers under
+    -fsanitize=address,undefined -fno-sanitize-recover=all (the reference runs with its validation layer always on,
+    VulkanHelper.cs:14-17): any out-of-bounds or undefined operation aborts the child."""
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    subprocess.check_call(["make", "-C", here, "-B", "san_driver"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(here, "san_driver")], capture_output=True, text=True, timeout=300,
+                       env={**os.environ, "ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1"})
+    assert r.returncode == 0 and "san_driver: ok" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
