@@ -33,6 +33,19 @@ public sealed unsafe class HipPipeline : IDisposable
     public void RecvHidden(nint hiddenDev, uint nFloats, uint peer) => Native.Check(Native.nfai_hip_pp_recv_hidden(handle, (void*)hiddenDev, nFloats, peer));
     public void SendToken(nint tokenDev, uint peer) => Native.Check(Native.nfai_hip_pp_send_token(handle, (void*)tokenDev, peer));
     public void RecvToken(nint tokenDev, uint peer) => Native.Check(Native.nfai_hip_pp_recv_token(handle, (void*)tokenDev, peer));
+    /// <summary>A whole tick in one native call (group start, the operations, group end).</summary>
+    public void Exchange(ReadOnlySpan<PpOp> ops)
+    {
+        fixed (PpOp* p = ops) Native.Check(Native.nfai_hip_pp_exchange(handle, p, (uint)ops.Length));
+    }
+    /// <summary>What RCCL reports for this communicator: (ranks, this rank, device ordinal, PCI bus id).</summary>
+    public (uint NRanks, uint Rank, int Device, string BusId) Info()
+    {
+        uint n, r; int d;
+        var bus = stackalloc byte[32];
+        Native.Check(Native.nfai_hip_pp_info(handle, &n, &r, &d, bus));
+        return (n, r, d, System.Runtime.InteropServices.Marshal.PtrToStringUTF8((nint)bus) ?? "");
+    }
     public void BroadcastToken(nint tokenDev, uint root) => Native.Check(Native.nfai_hip_pp_bcast_token(handle, (void*)tokenDev, root));
 
     public void Dispose()

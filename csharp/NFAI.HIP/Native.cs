@@ -24,6 +24,14 @@ public unsafe struct DeviceInfo
     public uint ComputeUnits, WavefrontSize, LdsBytesPerCu, ClockKhz;
 }
 
+/// <summary>nfai_pp_op (include/nfai_hip.h): one send / receive of a pipeline tick (nfai_hip_pp_exchange).</summary>
+[StructLayout(LayoutKind.Sequential)]
+public unsafe struct PpOp
+{
+    public void* Buf;
+    public uint Count, Peer, Kind, Reserved;   // Kind: 0 send hidden, 1 receive hidden, 2 send token, 3 receive token
+}
+
 /// <summary>ggml tensor type ids as stored in GGUF (Parser.cs:262-293 names the same ids).</summary>
 public enum GgmlType { F32 = 0, F16 = 1, Q4_K = 12, Q6_K = 14 }
 

@@ -313,6 +313,19 @@ int32_t nfai_hip_pp_recv_hidden(nfai_pp_t pp, void *hidden_dev, uint32_t n_float
 int32_t nfai_hip_pp_send_token(nfai_pp_t pp, const void *token_dev, uint32_t peer);   /* one uint32 */
 int32_t nfai_hip_pp_recv_token(nfai_pp_t pp, void *token_dev, uint32_t peer);
 int32_t nfai_hip_pp_bcast_token(nfai_pp_t pp, void *token_dev, uint32_t root);        /* in place, every rank */
+/* A tick's whole exchange in one call: group start, the listed sends / receives, group end (same stream, same semantics as the
+ * per-operation entry points between _begin and _end). */
+typedef struct nfai_pp_op {
+    void *buf;        /* device pointer */
+    uint32_t count;   /* floats (kinds 0, 1); ignored for tokens */
+    uint32_t peer;
+    uint32_t kind;    /* 0 send hidden, 1 receive hidden, 2 send token, 3 receive token */
+    uint32_t reserved;
+} nfai_pp_op;
+int32_t nfai_hip_pp_exchange(nfai_pp_t pp, const nfai_pp_op *ops, uint32_t n_ops);
+/* RCCL's own view of the communicator (ncclCommCount, ncclCommUserRank, ncclCommCuDevice) and the device's PCI bus id
+ * (32-byte buffer): for run records.  Any output may be NULL. */
+int32_t nfai_hip_pp_info(nfai_pp_t pp, uint32_t *nranks, uint32_t *rank, int32_t *device, char *pci_bus_id32);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,10 @@ class LlamaDescC(C.Structure):
         ("flags", C.c_uint32), ("max_batch", C.c_uint32)]
 
 
+class PpOp(C.Structure):
+    _fields_ = [("buf", C.c_void_p), ("count", C.c_uint32), ("peer", C.c_uint32), ("kind", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 u64, u32, i32, f32, vp = C.c_uint64, C.c_uint32, C.c_int32, C.c_float, C.c_void_p
 H = u64  # handles
 
@@ -117,6 +121,8 @@ SIGNATURES = {
     "nfai_hip_pp_send_token": [H, vp, u32],
     "nfai_hip_pp_recv_token": [H, vp, u32],
     "nfai_hip_pp_bcast_token": [H, vp, u32],
+    "nfai_hip_pp_exchange": [H, vp, u32],
+    "nfai_hip_pp_info": [H, C.POINTER(u32), C.POINTER(u32), C.POINTER(i32), C.c_char_p],
 }
 
 _lib = None

@@ -33,6 +33,9 @@ struct Rccl {
     Result (*GetUniqueId)(UniqueId *) = nullptr;
     Result (*CommInitRank)(Comm *, int, UniqueId, int) = nullptr;
     Result (*CommDestroy)(Comm) = nullptr;
+    Result (*CommCount)(Comm, int *) = nullptr;
+    Result (*CommUserRank)(Comm, int *) = nullptr;
+    Result (*CommCuDevice)(Comm, int *) = nullptr;
     Result (*Send)(const void *, size_t, int, int, Comm, hipStream_t) = nullptr;
     Result (*Recv)(void *, size_t, int, int, Comm, hipStream_t) = nullptr;
     Result (*Broadcast)(const void *, void *, size_t, int, int, Comm, hipStream_t) = nullptr;
@@ -62,6 +65,9 @@ Rccl *rccl()
         SYM(GetUniqueId, "ncclGetUniqueId")
         SYM(CommInitRank, "ncclCommInitRank")
         SYM(CommDestroy, "ncclCommDestroy")
+        SYM(CommCount, "ncclCommCount")
+        SYM(CommUserRank, "ncclCommUserRank")
+        SYM(CommCuDevice, "ncclCommCuDevice")
         SYM(Send, "ncclSend")
         SYM(Recv, "ncclRecv")
         SYM(Broadcast, "ncclBroadcast")
@@ -212,3 +218,55 @@ NFAI_API int32_t nfai_hip_pp_bcast_token(nfai_pp_t h, void *token_dev, uint32_t 
     NCCL_TRY(r, r->Broadcast(token_dev, token_dev, 1, DT_UINT32, (int)root, p->comm, p->ctx->stream));
     return NFAI_OK;
 }
+
+// What RCCL itself says about this communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice) plus the PCI bus id of the
+// device: bench.py puts it into its JSON line so that "did RCCL see N ranks on N different devices" can be read off the record.
+NFAI_API int32_t nfai_hip_pp_info(nfai_pp_t h, uint32_t *nranks, uint32_t *rank, int32_t *device, char *pci_bus_id32)
+{
+    PP_OR_FAIL(p, h);
+    RCCL_OR_FAIL(r);
+    int n = 0, me = 0, dev = -1;
+    NCCL_TRY(r, r->CommCount(p->comm, &n));
+    NCCL_TRY(r, r->CommUserRank(p->comm, &me));
+    NCCL_TRY(r, r->CommCuDevice(p->comm, &dev));
+    if (nranks) *nranks = (uint32_t)n;
+    if (rank) *rank = (uint32_t)me;
+    if (device) *device = dev;
+    if (pci_bus_id32) {
+        pci_bus_id32[0] = 0;
+        HIP_TRY(hipDeviceGetPCIBusId(pci_bus_id32, 32, dev));
+    }
+    return NFAI_OK;
+}
+
+// One tick's exchange in ONE call: ncclGroupStart, every send / receive of the tick, ncclGroupEnd, all on the stage stream.  The
+// host side of a tick is then this call plus the stage's graph launch (per-operation calls from a managed host cost several
+// microseconds each; at 8 stages a stage's device time per tick is ~0.2 ms).  kind: 0 send hidden, 1 receive hidden (count
+// floats), 2 send token, 3 receive token (one uint32).
+NFAI_API int32_t nfai_hip_pp_exchange(nfai_pp_t h, const nfai_pp_op *ops, uint32_t n_ops)
+{
+    PP_OR_FAIL(p, h);
+    RCCL_OR_FAIL(r);
+    if (n_ops == 0) return NFAI_OK;
+    if (!ops) return fail(NFAI_ERR_INVALID, "pp_exchange: null operation list");
+    if (p->in_group) return fail(NFAI_ERR_STATE, "pp_exchange: a group is already open");
+    for (uint32_t i = 0; i < n_ops; i++)
+        if (!ops[i].buf || ops[i].peer >= p->world || ops[i].kind > 3 || (ops[i].kind < 2 && ops[i].count == 0))
+            return fail(NFAI_ERR_INVALID, "pp_exchange: bad operation %u (kind %u, peer %u of %u)", i, ops[i].kind, ops[i].peer, p->world);
+    NCCL_TRY(r, r->GroupStart());
+    Result first_err = 0;
+    for (uint32_t i = 0; i < n_ops && first_err == 0; i++) {
+        const nfai_pp_op &o = ops[i];
+        switch (o.kind) {
+            case 0: first_err = r->Send(o.buf, o.count, DT_FLOAT32, (int)o.peer, p->comm, p->ctx->stream); break;
+            case 1: first_err = r->Recv(o.buf, o.count, DT_FLOAT32, (int)o.peer, p->comm, p->ctx->stream); break;
+            case 2: first_err = r->Send(o.buf, 1, DT_UINT32, (int)o.peer, p->comm, p->ctx->stream); break;
+            default: first_err = r->Recv(o.buf, 1, DT_UINT32, (int)o.peer, p->comm, p->ctx->stream); break;
+        }
+    }
+    const Result end_err = r->GroupEnd();  // always closed, also after a failed post
+    if (first_err != 0) return fail(NFAI_ERR_HIP, "pp_exchange: a send / receive failed: %s", r->GetErrorString(first_err));
+    if (end_err != 0) return fail(NFAI_ERR_HIP, "pp_exchange: ncclGroupEnd failed: %s", r->GetErrorString(end_err));
+    return NFAI_OK;
+}
+

@@ -18,6 +18,7 @@ from __future__ import annotations
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -181,6 +182,7 @@ class RcclComm:
         h = _lib.H()
         _lib.call("nfai_hip_pp_init", mgr.handle, rank, world, uid, C.byref(h))
         self.handle = h
+        self._ops = {}
 
     @staticmethod
     def unique_id() -> bytes:
@@ -191,6 +193,21 @@ class RcclComm:
         return bytes(uid)
 
     def exchange(self, sends, recvs):
+        """One tick: ONE native call (nfai_hip_pp_exchange: group start, sends, receives, group end on the stage stream).  The
+        (buffer, peer) pattern of a tick repeats every `world` ticks, so each operation array is built once."""
+        key = (tuple((t.data_ptr(), dst) for t, dst in sends), tuple((t.data_ptr(), src) for t, src in recvs))
+        ops = self._ops.get(key)
+        if ops is None:
+            PpOp = self._lib.PpOp
+            lst = [PpOp(t.data_ptr(), t.numel(), dst, 2 if t.numel() == 1 else 0, 0) for t, dst in sends]
+            lst += [PpOp(t.data_ptr(), t.numel(), src, 3 if t.numel() == 1 else 1, 0) for t, src in recvs]
+            ops = ((PpOp * len(lst))(*lst), len(lst))
+            self._ops[key] = ops
+        self._lib.call("nfai_hip_pp_exchange", self.handle, self._C.cast(ops[0], self._C.c_void_p), ops[1])
+
+    def exchange_per_op(self, sends, recvs):
+        """The same tick through the per-operation entry points (begin / send / receive / end), as a host without the array
+        form would issue it."""
         C, call = self._C, self._lib.call
         call("nfai_hip_pp_begin", self.handle)
         for t, dst in sends:
@@ -204,6 +221,14 @@ class RcclComm:
             else:
                 call("nfai_hip_pp_recv_hidden", self.handle, C.c_void_p(t.data_ptr()), t.numel(), src)
         call("nfai_hip_pp_end", self.handle)
+
+    def info(self) -> dict:
+        """RCCL's own view: ncclCommCount, ncclCommUserRank, ncclCommCuDevice + the device's PCI bus id."""
+        C = self._C
+        n, r, d = C.c_uint32(), C.c_uint32(), C.c_int32()
+        bus = C.create_string_buffer(32)
+        self._lib.call("nfai_hip_pp_info", self.handle, C.byref(n), C.byref(r), C.byref(d), bus)
+        return {"nranks": n.value, "rank": r.value, "device": d.value, "pci_bus_id": bus.value.decode()}
 
     def close(self):
         if self.handle is not None:
@@ -334,7 +359,33 @@ def run_bench_pipeline(args):
         else:
             comm = TorchComm(dist, stage_through_host=rehearsal)
         toks =[(128000 + 17 * s) % dims.V for s in range(world)]
-        # context fill + warmup (also instantiates the RCCL channels and the stage graphs)
+        # RCCL's own record of the communicator, gathered over gloo: the line shows that RCCL saw `world` ranks on `world` devices
+        rccl_view = None
+        if use_cabi:
+            views = [None] * world
+            dist.all_gather_object(views, comm.info())
+            rccl_view = {"nranks": views[0]["nranks"], "ranks": sorted(views, key=lambda v: v["rank"]),
+                         "distinct_devices": len({v["pci_bus_id"] for v in views})}
+        # The first exchanges open the RCCL channels (xGMI peer mappings, proxy threads).  A rank that never gets there (a peer
+        # missing, a transport that cannot be set up) would leave every other rank waiting inside RCCL for ever: a watchdog
+        # bounds the first `world` + 1 ticks and leaves the process with a message naming rank and stage (exit code 3; the
+        # launcher then ends the other ranks).  Never a re-exec.
+        first_ticks = threading.Event()
+        limit = float(os.environ.get("NFAI_PP_INIT_TIMEOUT", "240"))
+
+        def watchdog():
+            if not first_ticks.wait(limit):
+                print(f"[rank {rank}] stage blocks [{lb},{le}) of {dims.name}: the first pipeline exchanges did not complete within {limit:.0f} s "
+                      f"(exchange: {'nfai_hip_pp_* / RCCL' if use_cabi else 'torch.distributed'}); giving up", file=sys.stderr, flush=True)
+                os._exit(3)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        run_schedule(stage, comm, rank, world, world + 1, toks)
+        stream.synchronize()
+        first_ticks.set()
+        # context fill + warmup (also instantiates the stage graphs); the sequences restart from their first tokens
+        for mdl in stage.models:
+            mdl.Reset()
         run_schedule(stage, comm, rank, world, args.context + args.warmup, toks)
         stream.synchronize()
         dist.barrier()
@@ -368,7 +419,9 @@ def run_bench_pipeline(args):
                                    f"{world} independent batch-1 greedy sequences in flight over a {world}-stage layer pipeline, "
                                    f"{args.steps} tokens each after a {args.context}-token context",
                        "parallelism": f"pp{world}", "layer_ranges": ranges, "kv_capacity": C,
-                       "exchange": "nfai_hip_pp_* (RCCL send/recv on the stage stream)" if use_cabi else ("gloo via host (one-card rehearsal)" if rehearsal else "torch.distributed nccl")},
+                       "exchange": "nfai_hip_pp_exchange (RCCL send/recv, one group per tick on the stage stream)" if use_cabi else ("gloo via host (one-card rehearsal)" if rehearsal else "torch.distributed nccl"),
+                       "rccl": rccl_view,
+                       "command": f"python bench.py --gpus {world} --model {args.model} --quant {args.quant} --steps {args.steps} --warmup {args.warmup}"},
             "roofline": {"bound": "hbm", "achieved": float(gb.item()) * args.steps / dt / world, "peak": B.HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": float(gb.item()) * args.steps / dt / world / B.HBM_PEAK_GBPS, "traffic": None,
                          "kernel": "per-GPU average over the whole step (all kernels of the stage)"},

@@ -66,12 +66,15 @@ def stage_weights(dev, dims, lb, le, first, last):
 
 
 @pytest.mark.parametrize("quant", [False, True], ids=["f16", "q4_k_m"])
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_stages_through_schedule_in_process(env, world, quant):
     torch, stream, mgr = env
+    from dataclasses import replace
     from nfai_amd.pipeline import HipStage, partition_layers, run_schedule_in_process
     dims = synth.TINY_D128  # 3 blocks, untied lm_head
-    n_steps, C = 12, 32
+    if world == 8:          # BASELINE config 5's shape of the schedule: 8 stages, 8 sequences in flight, one block per stage
+        dims = replace(dims, L=8, name=dims.name + "-8blk")
+    n_steps, C = (12, 32) if world < 8 else (6, 16)
     with torch.cuda.stream(stream):
         dev, host = device_weights(torch, dims, quant)
         ranges = partition_layers(dims.L, world)
@@ -94,6 +97,41 @@ def test_stages_through_schedule_in_process(env, world, quant):
         assert all(m.BytesPerToken(0)[0] == b0 for m in st.models)
     for st in stages:
         st.dispose()
+
+
+def test_two_stages_at_8b_widths(env):
+    """Two stages of ONE block each at the Llama-3.1-8B widths (E 4096, 32 / 8 heads of 128, F 14336: the kernels and launch
+    geometries BASELINE config 5 runs), vocabulary cut to 2048: both in-flight sequences must produce exactly the tokens of a
+    single-stage greedy decode of the same two blocks on the GPU (a stage is a slice of the block loop: bit-identical)."""
+    torch, stream, mgr = env
+    from dataclasses import replace
+    from nfai_amd.llama_model import LlamaModel
+    from nfai_amd.pipeline import HipStage, run_schedule_in_process
+    dims = replace(synth.LLAMA_31_8B, L=2, V=2048, name="llama-3.1-8b-2blk")
+    n_steps, C, world = 8, 16, 2
+    with torch.cuda.stream(stream):
+        g = torch.Generator(device="cuda")
+        g.manual_seed(5)
+        dev = {}
+        for name, shape in dims.shapes().items():
+            if len(shape) == 1:
+                dev[name] = (1.0 + 0.1 * torch.randn(shape, device="cuda", generator=g), 0, 1, shape[0])
+            else:
+                dev[name] = ((0.02 * torch.randn(shape, device="cuda", generator=g)).half(), 1, shape[0], shape[1])
+        stages = [HipStage(torch, mgr, dims, (r, r + 1), stage_weights(dev, dims, r, r + 1, r == 0, r == 1), world, C, r, world) for r in range(2)]
+        first = [7, 1234]
+        run_schedule_in_process(stages, n_steps, first, lambda dst, src: dst.copy_(src))
+        stream.synchronize()
+        got = [stages[-1].models[s].FetchTokens(n_steps).tolist() for s in range(world)]
+        tens = {k: (t.data_ptr(), ty, rows, cols) for k, (t, ty, rows, cols) in dev.items()}
+        d = dict(E=dims.E, L=dims.L, H=dims.H, Hkv=dims.Hkv, D=dims.D, F=dims.F, V=dims.V, eps=1e-5, rope_dims=dims.D, rope_base=500000.0)
+        whole = LlamaModel(mgr, {"general.name": dims.name}, tens, C, dims=d)
+        for s in range(world):
+            assert got[s] == whole.Greedy(first[s], n_steps).tolist()
+            whole.Reset()
+        whole.Dispose()
+        for st in stages:
+            st.dispose()
 
 
 def test_single_stage_schedule_world1(env):
@@ -126,9 +164,20 @@ def test_rccl_exchange_one_rank(env):
         ta = torch.tensor([123456], device="cuda", dtype=torch.int32)
         tb = torch.zeros(1, device="cuda", dtype=torch.int32)
         stream.synchronize()
-        comm.exchange([(a, 0), (ta, 0)], [(b, 0), (tb, 0)])
+        comm.exchange([(a, 0), (ta, 0)], [(b, 0), (tb, 0)])           # one native call per tick (nfai_hip_pp_exchange)
         stream.synchronize()
         assert torch.equal(a, b) and int(tb.item()) == 123456
+        b.zero_(); tb.zero_()
+        comm.exchange([(a, 0), (ta, 0)], [(b, 0), (tb, 0)])           # the cached operation array of the repeating pattern
+        comm.exchange_per_op([(b, 0)], [(a, 0)])                        # and the per-operation entry points
+        stream.synchronize()
+        assert torch.equal(a, b) and int(tb.item()) == 123456
+        view = comm.info()                                              # RCCL's own record of the communicator
+        assert view["nranks"] == 1 and view["rank"] == 0 and view["device"] == 0 and len(view["pci_bus_id"]) >= 7
+        from nfai_amd import _lib as L
+        with pytest.raises(L.NfaiHipError, match="bad operation"):
+            bad = (L.PpOp * 1)(L.PpOp(a.data_ptr(), 8, 5, 0, 0))       # peer 5 of 1
+            L.call("nfai_hip_pp_exchange", comm.handle, bad, 1)
         import ctypes as C
         from nfai_amd import _lib
         _lib.call("nfai_hip_pp_bcast_token", comm.handle, C.c_void_p(tb.data_ptr()), 0)
