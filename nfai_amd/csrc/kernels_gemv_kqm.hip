@@ -188,6 +188,8 @@ __global__ __launch_bounds__(1024) void k_gemv_kqt(const KqmParams p)
 
     const uint32_t nunits = (p.NU - blockIdx.x + gridDim.x - 1) / gridDim.x;
     const uint32_t nsteps = nunits * R * BPW;  // step = (unit, tile of the unit, super-block of this wave)
+    STAMP_DECL;
+    STAMP(0);  // wave started
 
     // ---- activations first (vmcnt is in order: what the prologue needs must not queue behind weights).
     // Wave w loads, scales and stages exactly the super-blocks it will consume (w*BPW .. w*BPW+BPW-1): the fixed-point
@@ -234,10 +236,18 @@ __global__ __launch_bounds__(1024) void k_gemv_kqt(const KqmParams p)
     };
 #pragma unroll
     for (int j = 0; j < NBUF; j++) issue(buf[j]);
+    STAMP(1);  // activation loads and the first weight steps issued
 
-    // ---- prologue: RMSNorm, per-super-block power-of-two scale, three base-256 digits -> LDS, scale-group sums
+    // ---- prologue: per-super-block power-of-two scale, three base-256 digits -> LDS, scale-group sums.
+    // RMSNorm (RMSNormShader.cs:136-149: (x / rms) * g) is applied in two parts: the gains here, element by element (u = x * g), the
+    // division by rms = sqrt(mean(x^2) + eps) on the finished dot products in the epilogue — it is one scalar per vector, and
+    // waiting for it here meant a workgroup barrier on the slowest wave's x, whose request sits behind every other wave's first
+    // weight requests in the CU's in-order memory queue (stamps, round 3: x staged at 2.7-3.4 us with the barrier, 0.8 us without;
+    // 3B Q4_K_M 1026 -> 1088 tokens/s).  Every wave stages exactly the super-blocks it consumes, so nothing here waits for another
+    // wave; its share of sum(x^2) goes to LDS and is combined in fixed wave order behind the barrier the cross-wave reduction needs
+    // anyway.  The fixed-point rounding of u (24 bits relative to the super-block's maximum) dominates the two roundings the
+    // reordering moves.
     {
-        float rms = 1.f;
         if constexpr (NORM) {
             float ss = 0.f;
 #pragma unroll
@@ -246,29 +256,22 @@ __global__ __launch_bounds__(1024) void k_gemv_kqt(const KqmParams p)
                 for (int e = 0; e < 4; e++) ss = fmaf(xv[i][e], xv[i][e], ss);
             ss = wave_sum(ss);
             if (lane == 0) scal[wid] = ss;
-            __syncthreads();
-            float tss = 0.f;
-#pragma unroll
-            for (uint32_t i = 0; i < 16; i++) {  // fixed trip count: the LDS reads issue back to back
-                const float s_i = scal[min(i, nw - 1)];
-                tss += i < nw ? s_i : 0.f;
-            }
-            rms = sqrtf(tss / (float)p.K + p.eps);
         }
 #pragma unroll
         for (int i = 0; i < BPW; i++) {
-            const uint32_t blk = wid * BPW + i, k = lane * 4;  // position inside the super-block
+            const uint32_t blk = wid * BPW + i;
             f32x4 v = xv[i];
             if constexpr (NORM) {
-                v[0] = (v[0] / rms) * gv[i][0];
-                v[1] = (v[1] / rms) * gv[i][1];
-                v[2] = (v[2] / rms) * gv[i][2];
-                v[3] = (v[3] / rms) * gv[i][3];
+                v[0] = v[0] * gv[i][0];
+                v[1] = v[1] * gv[i][1];
+                v[2] = v[2] * gv[i][2];
+                v[3] = v[3] * gv[i][3];
             }
             kqm_stage<HAS4, HAS6>(v, blk, lane, xa, xa6, sums, sums6, scl);
         }
         // no barrier: every LDS word written above is read only by this wave (LDS operations of a wave execute in order)
     }
+    STAMP(2);  // x normalised, scaled and staged as digits in LDS
 
     const uint32_t g = lane >> 4, ra = lane & 15;
     const bool a_live = (ra >> 2) == g && (ra & 3) < 3;  // A rows 4G, 4G+1, 4G+2 = digits 0, 1, 2 of lane group G
@@ -321,6 +324,16 @@ __global__ __launch_bounds__(1024) void k_gemv_kqt(const KqmParams p)
                 if (wid <= slot) {  // wave q finishes unit q of this round
                     const uint32_t uq = blockIdx.x + (ui - slot + wid) * gridDim.x;
                     const KqmPre pre = ui == slot ? pre0 : kqm_preload<MODE>(p, uq, lane);
+                    float rms = 1.f;
+                    if constexpr (NORM) {  // every wave's share of sum(x^2) is in LDS (written before its first step, barrier above)
+                        float tss = 0.f;
+#pragma unroll
+                        for (uint32_t i = 0; i < 16; i++) {  // fixed trip count and order: the LDS reads issue back to back
+                            const float s_i = scal[min(i, nw - 1)];
+                            tss += i < nw ? s_i : 0.f;
+                        }
+                        rms = sqrtf(tss / (float)p.K + p.eps);
+                    }
                     float af[R];
 #pragma unroll
                     for (int t2 = 0; t2 < R; t2++) {
@@ -333,6 +346,7 @@ __global__ __launch_bounds__(1024) void k_gemv_kqt(const KqmParams p)
                         }
                         float s = (sp[0] + sp[1]) + (sp[2] + sp[3]);
                         af[t2] = rows4_sum(s);
+                        if constexpr (NORM) af[t2] = af[t2] / rms;
                     }
                     kqm_epilogue<MODE>(p, uq, lane, af[0], af[R - 1], pre, best_v, best_i);
                 }
@@ -343,10 +357,24 @@ __global__ __launch_bounds__(1024) void k_gemv_kqt(const KqmParams p)
 
     if constexpr (NS > 0) {
 #pragma unroll
-        for (int j = 0; j < NS; j++)
+        for (int j = 0; j < NS; j++) {
             if ((uint32_t)j < nsteps) consume(buf[j]);
+            if (j == 0) STAMP(3);  // first weight step landed, multiplied (and, with one step per unit, reduced)
+        }
     } else {
         uint32_t st = 0;
+#ifdef NFAI_STAMPS
+        if (nsteps > 4) {
+            consume(buf[0]);
+            STAMP(3);
+            issue(buf[0]);
+            consume(buf[1]);
+            issue(buf[1]);
+            st = 2;
+        } else {
+            STAMP(3);
+        }
+#endif
         for (; st + 3 < nsteps; st += 2) {
             consume(buf[0]);
             issue(buf[0]);
@@ -366,6 +394,12 @@ __global__ __launch_bounds__(1024) void k_gemv_kqt(const KqmParams p)
             consume(buf[0]);
         }
     }
+#ifdef NFAI_STAMPS
+    STAMP(4);  // last step consumed, reductions and epilogue stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(5);  // stores acknowledged
+    STAMP_FLUSH(p.stamps, blockIdx.x * nw + wid, 6);
+#endif
     if constexpr (MODE == GEMV_PLAIN) {
         // SamplingUtils.ArgMax over the outputs in the same launch (block-uniform: a kernel argument); its 48 LDS words sit behind `scal`
         if (p.am.ticket != nullptr) argmax_fused_tail(best_v, best_i, p.am, reinterpret_cast<uint32_t *>(scal + 32));
@@ -662,6 +696,10 @@ hipError_t launch_gemv_kqm(const GemvArgs &a, hipStream_t s)
     while (p.UB > 1 && lds_bytes(p.UB) > 160 * 1024) p.UB--;  // very long K: fewer units per reduction round
     const size_t lds = lds_bytes(p.UB);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    {
+        static const char *names[] = {"kqm_plain", "kqm_residual", "kqm_qkv_rope", "kqm_gateup"};
+        NFAI_STAMP_SET(p, names[a.mode & 3], grid, nw * 64);
+    }
     if (a.w_type == NFAI_KQ_MIXED) return q4t_bpw<NFAI_KQ_MIXED, GEMV_QKV_ROPE>(p, bpw, grid, nw * 64, lds, s);
     if (a.w_type == NFAI_Q4_K_T16) {
         switch (a.mode) {

@@ -31,6 +31,7 @@ struct KqmParams {
     const uint32_t *pos;
     int kv_f16;
     ArgmaxFused am;            // GEMV_PLAIN: first index of the largest output, taken in this launch (am.ticket == nullptr: off)
+    NFAI_STAMP_PARAM
 };
 
 struct Q4T { u32x4 q0, q1, hdr; };
