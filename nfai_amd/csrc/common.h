@@ -101,6 +101,23 @@ struct GemvArgs {
     const uint32_t *pos_dev = nullptr;  // current position (device scalar)
     uint32_t n_cu = 256;
     bool prefetch_only = false;  // side-stream launch that only touches the first two steps of every wave's weights
+    // GEMV_QKV_ROPE with RMSNorm only — the per-token prologue folded into the FIRST q|k|v launch of a token (LlamaModel.cs:116 +
+    // the RoPE angles RoPEShader.cs:254-256 recomputes per element): begin.on: the activation vector is row tok[0] of the
+    // embedding table `emb` (emb == nullptr: x as usual, e.g. a pipeline stage that received its hidden state), workgroup 0 also
+    // stores it to x_out (later launches read it as the residual), writes the cos/sin table of the current position for the
+    // other blocks' launches and advances the hand-off epoch; this launch's own RoPE forms cos/sin itself
+    struct Begin {
+        bool on = false;
+        const void *emb = nullptr;   // [emb_rows][K]: F16 / F32 row-major, or the T16 layout of a Q4_K / Q6_K table
+        int emb_type = NFAI_F16;
+        uint64_t emb_rows = 0;
+        const uint32_t *tok = nullptr;
+        float *x_out = nullptr;
+        const float *freqs = nullptr;  // [n_freq] RoPE frequencies (TransformerBlock.cs:33-38)
+        float *cs_out = nullptr;       // [n_freq][2]
+        uint32_t n_freq = 0;
+        uint32_t *epoch = nullptr;
+    } begin;
     // GEMV_PLAIN only: SamplingUtils.ArgMax over the N outputs in the same launch (the lm_head): argmax_part = workspace of
     // argmax_fused_bytes() bytes, zeroed once; the first index of the maximum -> argmax_out; then, if argmax_pos_inc != nullptr, the
     // end-of-token bookkeeping of launch_argmax (ring[pos % ring_len] = token, ++pos)
@@ -119,6 +136,7 @@ inline bool is_kquant(int t) { return t == NFAI_Q4_K || t == NFAI_Q6_K || t == N
 inline int ggml_type_of(int t) { return t == NFAI_Q4_K_T16 ? NFAI_Q4_K : (t == NFAI_Q6_K_T16 ? NFAI_Q6_K : t); }
 
 hipError_t launch_gemv(const GemvArgs &a, hipStream_t s);     // any weight type; K-quants go to launch_gemv_kq / _kqm
+bool gemv_begin_ok(const GemvArgs &a);                         // can this q|k|v launch carry the per-token prologue (GemvArgs::Begin)?
 hipError_t launch_gemv_kq(const GemvArgs &a, hipStream_t s);  // Q4_K (native blocks) / Q6_K (plane layout)
 hipError_t launch_gemv_kqm(const GemvArgs &a, hipStream_t s); // Q4_K_T16: MFMA dot products
 hipError_t launch_repack_q4k_t16(const void *native, void *tiled, uint64_t rows, uint64_t cols, hipStream_t s);
@@ -366,6 +384,91 @@ __device__ __forceinline__ float dot8_f16(u32x4 w, f32x4 x0, f32x4 x1, float acc
     acc = fmaf(h2f_hi(w[3]), x1[3], acc);
     return acc;
 }
+
+// ---- the per-token prologue inside the first q|k|v launch (GemvArgs::Begin) -------------------------------------------------------
+struct BeginParams {
+    const uint8_t *emb;
+    uint64_t emb_rows;
+    const uint32_t *tok;
+    float *x_out;
+    const float *freqs;
+    float *cs_out;
+    uint32_t *epoch;
+    uint32_t n_freq;
+    int emb_type;
+    uint32_t on;
+};
+
+// four consecutive elements k .. k+3 (k % 4 == 0) of row `row` of an embedding table with E columns, widened to fp32 exactly as
+// TokenEmbedShader (TokenEmbedShader.cs:131-159) / k_embed_q4t / k_embed_q6t give them
+__device__ __forceinline__ f32x4 embed_load4(const uint8_t *table, int type, uint64_t n_rows, uint64_t row, uint32_t k, uint32_t E)
+{
+    typedef __attribute__((address_space(1))) uint8_t g8;
+    const g8 *t = (const g8 *)table;
+    if (type == NFAI_F16) {
+        const u32x2 w = *reinterpret_cast<const __attribute__((address_space(1))) u32x2 *>(t + (row * E + k) * 2);
+        return f32x4{h2f_lo(w[0]), h2f_hi(w[0]), h2f_lo(w[1]), h2f_hi(w[1])};
+    }
+    if (type == NFAI_F32) return *reinterpret_cast<const __attribute__((address_space(1))) f32x4 *>(t + (row * E + k) * 4);
+    const uint32_t NB = E / 256, blk = k >> 8, kk = k & 255;
+    const uint64_t tile = row >> 4, r = row & 15, tb = tile * NB + blk, nblk = n_rows * NB;
+    f32x4 out;
+    if (type == NFAI_Q4_K_T16) {  // k_embed_q4t
+        const uint32_t sb = kk >> 5, l = kk & 31;
+        const g8 *hdr = t + nblk * 128 + tb * 256 + r * 16;
+        const float d = (float)*reinterpret_cast<const __attribute__((address_space(1))) _Float16 *>(hdr);
+        const float dmin = (float)*reinterpret_cast<const __attribute__((address_space(1))) _Float16 *>(hdr + 2);
+        const g8 *scales = hdr + 4;
+        uint32_t sc, m;
+        if (sb < 4) { sc = scales[sb] & 63; m = scales[sb + 4] & 63; }
+        else { sc = (scales[sb + 4] & 0xF) | ((scales[sb - 4] >> 6) << 4); m = (scales[sb + 4] >> 4) | ((scales[sb] >> 6) << 4); }
+        const uint32_t q4 = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>(t + tb * 2048 + (l >> 4) * 1024 + ((sb >> 1) * 16 + r) * 16 + (l & 15));
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const uint32_t q = (q4 >> (8 * e)) & 0xFFu;
+            out[e] = d * (float)sc * (float)((sb & 1) ? (q >> 4) : (q & 0xF)) - dmin * (float)m;
+        }
+    } else {  // NFAI_Q6_K_T16: k_embed_q6t
+        const uint32_t n = kk >> 7, qd = (kk >> 5) & 3, l = kk & 31, lh = l >> 4, b = l & 15;
+        const uint32_t ln = (n * 2 + lh) * 16 + (uint32_t)r;
+        const uint32_t ql4 = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>(t + tb * 3072 + (qd & 1) * 1024 + ln * 16 + b);
+        const uint32_t qh4 = *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>(t + tb * 3072 + 2048 + ln * 16 + b);
+        const int sc = (int)(int8_t)t[nblk * 192 + tb * 256 + r * 16 + 8 * n + lh + 2 * qd];
+        const float d = (float)reinterpret_cast<const __attribute__((address_space(1))) _Float16 *>(t + nblk * 208 + tb * 32)[r];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const uint32_t ql = (ql4 >> (8 * e)) & 0xFFu, qh = (qh4 >> (8 * e)) & 0xFFu;
+            const int q = (int)(((qd >= 2) ? (ql >> 4) : (ql & 0xF)) | (((qh >> (2 * qd)) & 3) << 4)) - 32;
+            out[e] = d * (float)sc * (float)q;
+        }
+    }
+    return out;
+}
+
+// cos / sin of RoPE pair `pair` at position pos, as k_token_begin tabulates them (RoPEShader.cs:254-256)
+__device__ __forceinline__ f32x2 rope_cs_of(const float *freqs, uint32_t pair, uint32_t pos)
+{
+    const float theta = ((const __attribute__((address_space(1))) float *)freqs)[pair] * (float)pos;
+    return f32x2{cosf(theta), sinf(theta)};
+}
+
+// First q|k|v launch of a token: every workgroup tabulates cos/sin of the position once, in LDS (cs_lds: 2 * n_freq floats, read by
+// its own RoPE epilogues behind a workgroup barrier; libm range reduction at theta ~ 1e2 is too slow to repeat per finished row);
+// workgroup 0 also writes the table for the other blocks' launches and advances the hand-off epoch.
+__device__ __forceinline__ void begin_bookkeeping(const BeginParams &b, uint32_t pos, float *cs_lds)
+{
+    for (uint32_t d = threadIdx.x; d < b.n_freq; d += blockDim.x) {
+        const f32x2 cs = rope_cs_of(b.freqs, d, pos);
+        cs_lds[2 * d] = cs[0];
+        cs_lds[2 * d + 1] = cs[1];
+        if (blockIdx.x == 0) {
+            b.cs_out[2 * d] = cs[0];
+            b.cs_out[2 * d + 1] = cs[1];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && b.epoch) b.epoch[0] = b.epoch[0] + 1;
+}
+constexpr uint32_t BEGIN_CS_WORDS = 128;  // LDS words of that table (head_dim <= 128)
 
 // ---- "first index of the largest value" across lanes / waves / workgroups (SamplingUtils.ArgMax, SamplingUtils.cs:55-56: values.Max()
 //      then IndexOf: the LOWEST index among equal maxima) ---------------------------------------------------------------------------

@@ -40,6 +40,7 @@ struct GemvParams {
     int kv_f16;
     uint32_t prefetch_only;  // 1: touch the first two steps of every wave's weights (default cache policy) and exit
     ArgmaxFused am;          // GEMV_PLAIN: first index of the largest output, taken in this launch (am.ticket == nullptr: off)
+    BeginParams begin;       // GEMV_QKV_ROPE, split-K form only: the per-token prologue in this launch (begin.on == 0: off)
     NFAI_STAMP_PARAM
 };
 
@@ -123,7 +124,7 @@ __device__ __forceinline__ void kv_store(void *base, int f16, uint64_t idx, floa
 // consumed so the latency is hidden behind the rest of the row (a load issued in the epilogue
 // itself would add a full memory round trip to every short kernel).  Unconditional, clamped.
 template <int MODE>
-__device__ __forceinline__ void epilogue_prefetch(const GemvParams &p, uint32_t unit, float &e0, float &e1)
+__device__ __forceinline__ void epilogue_prefetch(const GemvParams &p, uint32_t unit, float &e0, float &e1, const float *cs_lds = nullptr)
 {
     if constexpr (MODE == GEMV_RESIDUAL) {
         e0 = ((const GLOBAL_AS float *)p.res)[unit];
@@ -131,7 +132,9 @@ __device__ __forceinline__ void epilogue_prefetch(const GemvParams &p, uint32_t 
         const uint32_t row = unit * 2;
         const uint32_t r = row < p.seg_end[0] ? row : (row < p.seg_end[1] ? row - p.seg_end[0] : row - p.seg_end[1]);
         const uint32_t d = min(r % p.D, max(p.rope_dims, 2u) - 2);
-        const f32x2 cs = *reinterpret_cast<const GLOBAL_AS f32x2 *>((const GLOBAL_AS float *)p.rope_cs + d);  // [pair][2], pair = d/2
+        f32x2 cs;
+        if (cs_lds) cs = *reinterpret_cast<const f32x2 *>(cs_lds + d);  // first launch of a token (split-K form): the workgroup's own table
+        else cs = *reinterpret_cast<const GLOBAL_AS f32x2 *>((const GLOBAL_AS float *)p.rope_cs + d);  // [pair][2], pair = d/2
         e0 = cs[0];
         e1 = cs[1];
     }
@@ -182,9 +185,10 @@ struct StepWalk {
     }
 };
 
-template <int WT, int MODE, int UPW, int U, bool GUARD, bool NORM>
+template <int WT, int MODE, int UPW, int U, bool GUARD, bool NORM, bool BEGIN = false>
 __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
 {
+    static_assert(!BEGIN || (MODE == GEMV_QKV_ROPE && NORM), "the per-token prologue rides on the RMSNorm'd q|k|v launch");
     constexpr int RPU = (MODE == GEMV_QKV_ROPE || MODE == GEMV_GATEUP) ? 2 : 1;
     constexpr int R = UPW * RPU;
     constexpr int EPL = WTraits<WT>::EPL;
@@ -238,7 +242,13 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
         // hipcc wait vmcnt(0) per element
         const uint32_t k = (threadIdx.x + i * blockDim.x) * 4;
         const uint32_t kk = min(k, p.K - 4);
-        const f32x4 v = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.x + kk);
+        f32x4 v;
+        if (BEGIN && p.begin.emb) {  // first launch of a token: x is the token's embedding row; workgroup 0 stores it for the residual
+            v = embed_load4(p.begin.emb, p.begin.emb_type, p.begin.emb_rows, p.begin.tok[0], kk, p.K);
+            if (blockIdx.x == 0 && k < p.K) *reinterpret_cast<f32x4 *>(p.begin.x_out + kk) = v;
+        } else {
+            v = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.x + kk);
+        }
         xv[i] = k < p.K ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (NORM) gv[i] = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.gamma + kk);
     }
@@ -247,8 +257,10 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
     // lane q < UPW finishes unit q of each group: what its FIRST epilogue reads (residual element /
     // cos,sin pair) and the position are requested now, with the activations
     float e0 = 0.f, e1 = 0.f;
-    epilogue_prefetch<MODE>(p, min(min(u_begin + min(lane, (uint32_t)UPW - 1), u_end - 1), p.NU - 1), e0, e1);
+    float *cs_lds = BEGIN ? xs + kpad + 16 + 48 : nullptr;  // first launch of a token: cos / sin of the position tabulated in LDS
+    if constexpr (!BEGIN) epilogue_prefetch<MODE>(p, min(min(u_begin + min(lane, (uint32_t)UPW - 1), u_end - 1), p.NU - 1), e0, e1);
     const uint32_t pos_v = (MODE == GEMV_QKV_ROPE) ? p.pos[0] : 0u;
+    if constexpr (BEGIN) begin_bookkeeping(p.begin, pos_v, cs_lds);
 
     // ---- (2) weight loads of the first TWO steps (they do not depend on x) ----------------------
     u32x4 bufA[R][U], bufB[R][U];
@@ -292,7 +304,15 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
                 ss = fmaf(xv[i][2], xv[i][2], ss);
                 ss = fmaf(xv[i][3], xv[i][3], ss);
             }
+#ifdef NFAI_STAMPS
+            asm volatile("" ::"v"(ss));
+            STAMP(6);  // this wave's x has arrived (sum of squares of its own elements formed)
+#endif
             ss = block_sum<true>(ss, red);
+#ifdef NFAI_STAMPS
+            asm volatile("" ::"v"(ss));
+            STAMP(7);  // the workgroup's sum is known to this wave
+#endif
             rms = sqrtf(ss / (float)p.K + p.eps);
         }
 #pragma unroll
@@ -320,6 +340,7 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
 #ifndef GEMV_B_EARLY
     issue(bufB);
 #endif
+    if constexpr (BEGIN) epilogue_prefetch<MODE>(p, min(min(u_begin + min(lane, (uint32_t)UPW - 1), u_end - 1), p.NU - 1), e0, e1, cs_lds);  // (table: barrier above)
     STAMP(2);  // x (normalised) is in LDS, second weight step issued
 
     float acc[R];
@@ -352,7 +373,7 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
 #pragma unroll
             for (int r = 0; r < R; r++) acc[r] = 0.f;
             // what the NEXT group's epilogue reads, a whole group ahead
-            epilogue_prefetch<MODE>(p, min(min(u_begin + (cw.g + 1) * UPW + min(lane, (uint32_t)UPW - 1), u_end - 1), p.NU - 1), e0, e1);
+            epilogue_prefetch<MODE>(p, min(min(u_begin + (cw.g + 1) * UPW + min(lane, (uint32_t)UPW - 1), u_end - 1), p.NU - 1), e0, e1, cs_lds);
         }
         cw.next(cpg);
     };
@@ -400,8 +421,217 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
     STAMP(4);  // last FMA, reduction and epilogue stores issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(5);  // stores acknowledged
-    STAMP_FLUSH(p.stamps, gw, 6);
+    STAMP_FLUSH(p.stamps, gw, 8);
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same GEMV as MANY SHORT WORKGROUPS that split K over their waves (round 3).  k_gemv above keeps one or two long-running
+// workgroups per CU whose waves walk whole rows behind a workgroup-wide activation prologue (x -> RMSNorm -> LDS -> barrier): the
+// right shape for the 788 MB lm_head, but a per-block matrix of 19-100 MB pays that serial head and the slowest wave's tail once per
+// launch with nothing to overlap them with.  Here:
+//   workgroup = NW waves; wave w owns the K-slice [w * CH * 64 * EPL, +CH * 64 * EPL): ITS slice of x lives in registers — no LDS, no
+//               barrier in front of the stream; the workgroup owns RW consecutive rows (RW / 2 row pairs for the modes that finish
+//               rows in pairs); every wave requests its slice of all RW rows at once (RW * CH 16-byte loads per lane, straight to
+//               registers, non-temporal), multiplies as they land, reduces each row over the wave (DPP) and the waves meet ONCE, in
+//               LDS, at the end; thread t < RW / RPU then finishes unit t (same epilogues as k_gemv);
+//   grid      = rows / RW workgroups (hundreds to thousands): several are resident per CU, so the head of one overlaps the tail of
+//               another — which a persistent wave cannot do with itself;
+//   RMSNorm   = (sum_k w_k * (x_k * g_k)) / rms: the gains are applied element by element as in RMSNormShader.cs:136-149, the
+//               division by rms = sqrt(mean(x^2) + eps) — one scalar per vector — to the finished dot product, so no dot product
+//               waits for the whole of x (each wave adds its slice's sum of squares in LDS; combined in wave order at the end).
+//               The reordering moves two roundings of ~6e-8 relative per term; the tests' summation-order bound is 30x that.
+// tools/gemv_sk_bench.hip (profiles/round3_gemv_sk_bench.txt), us per launch in a chain of cold launches, k_gemv -> this form:
+// 3B q|k|v 7.9 -> 7.4, Wo 6.3 -> 4.9, gate|up 17.5 -> 17.3, Wdown 10.3 -> 9.9; 1B q|k|v 6.6 -> 4.5, gate|up 13.6 -> 12.1, Wdown 8.2 -> 7.3.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int SK_MAX_WAVES = 16;
+
+template <int WT, int MODE, int CH, int RW, bool NORM>
+__global__ __launch_bounds__(SK_MAX_WAVES * 64) void k_gemv_sk(const GemvParams p)
+{
+    constexpr int RPU = (MODE == GEMV_QKV_ROPE || MODE == GEMV_GATEUP) ? 2 : 1;
+    constexpr int RWU = RW / RPU;                       // units per workgroup
+    constexpr int EPL = WTraits<WT>::EPL;               // elements per 16-byte load: 8 (fp16) / 4 (fp32)
+    constexpr int EB = (WT == NFAI_F16) ? 2 : 4;
+    constexpr int XV = EPL / 4;                         // f32x4 of x per chunk and lane
+    __shared__ float part[RW][SK_MAX_WAVES];
+    __shared__ float ssq[SK_MAX_WAVES];
+    __shared__ uint32_t am_lds[48];
+    __shared__ float cs_tab[BEGIN_CS_WORDS];
+    const uint32_t lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t unit0 = blockIdx.x * RWU;
+    STAMP_DECL;
+    STAMP(0);  // wave started
+    const bool begin = MODE == GEMV_QKV_ROPE && NORM && p.begin.on;  // block-uniform
+    // ---- this wave's slice of the activations (and gains) first: vmcnt retires in order
+    f32x4 xa[CH][XV], ga[NORM ? CH : 1][XV];
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const uint32_t k = ((w * CH + c) * 64 + lane) * EPL;
+#pragma unroll
+        for (int h = 0; h < XV; h++) {
+            if (begin && p.begin.emb) {  // the token's embedding row (first launch of a token); workgroup 0 stores it for the residual
+                xa[c][h] = embed_load4(p.begin.emb, p.begin.emb_type, p.begin.emb_rows, p.begin.tok[0], k + 4 * h, p.K);
+                if (blockIdx.x == 0) *reinterpret_cast<f32x4 *>(p.begin.x_out + k + 4 * h) = xa[c][h];
+            } else {
+                xa[c][h] = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.x + k + 4 * h);
+            }
+            if constexpr (NORM) ga[c][h] = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.gamma + k + 4 * h);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // what unit t's epilogue reads besides the sums (residual element / cos, sin / position): thread t, now
+    float e0 = 0.f, e1 = 0.f;
+    const uint32_t my_unit = min(unit0 + min(threadIdx.x, (uint32_t)RWU - 1), p.NU - 1);
+    if (!begin) epilogue_prefetch<MODE>(p, my_unit, e0, e1);
+    const uint32_t pos_v = (MODE == GEMV_QKV_ROPE) ? p.pos[0] : 0u;
+    if (begin) begin_bookkeeping(p.begin, pos_v, cs_tab);  // cos / sin table of the position in LDS (+ global copy, epoch: workgroup 0)
+    // ---- every weight request of this wave at once
+    u32x4 wv[RW][CH];
+#pragma unroll
+    for (int r = 0; r < RW; r++) {
+        const uint8_t *row = row_ptr<MODE>(p, min(unit0 + r / RPU, p.NU - 1), r % RPU);
+#pragma unroll
+        for (int c = 0; c < CH; c++) wv[r][c] = load_nt16(row + (uint64_t)(((w * CH + c) * 64 + lane) * EPL) * EB);
+    }
+    STAMP(1);  // activation and weight requests issued
+    if constexpr (NORM) {
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; c++)
+#pragma unroll
+            for (int h = 0; h < XV; h++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    ss = fmaf(xa[c][h][e], xa[c][h][e], ss);
+                    xa[c][h][e] = xa[c][h][e] * ga[c][h][e];  // RMSNormShader.cs:148: (x / rms) * g, the division deferred
+                }
+        ss = wave_sum(ss);
+        if (lane == 0) ssq[w] = ss;
+    }
+    STAMP(2);  // this wave's x is in registers
+#pragma unroll
+    for (int r = 0; r < RW; r++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            if constexpr (WT == NFAI_F16) {
+                acc = dot8_f16(wv[r][c], xa[c][0], xa[c][XV - 1], acc);
+            } else {
+                const f32x4 wf = __builtin_bit_cast(f32x4, wv[r][c]);
+                acc = fmaf(wf[0], xa[c][0][0], acc);
+                acc = fmaf(wf[1], xa[c][0][1], acc);
+                acc = fmaf(wf[2], xa[c][0][2], acc);
+                acc = fmaf(wf[3], xa[c][0][3], acc);
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) part[r][w] = acc;
+        if (r == 0) STAMP(3);  // first row's slice landed and multiplied
+    }
+    __syncthreads();
+    // ---- thread t finishes unit t: the waves' partial sums in wave order, RMSNorm's division, the mode's epilogue
+    float best_v = -INFINITY;
+    uint32_t best_i = 0xFFFFFFFFu;
+    if (threadIdx.x < (uint32_t)RWU && unit0 + threadIdx.x < p.NU) {
+        const uint32_t t = threadIdx.x, unit = unit0 + t;
+        float a[RPU];
+#pragma unroll
+        for (int q = 0; q < RPU; q++) {
+            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < SK_MAX_WAVES; i++) s4[i & 3] += (uint32_t)i < nw ? part[t * RPU + q][min((uint32_t)i, nw - 1)] : 0.f;
+            a[q] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        }
+        if constexpr (NORM) {
+            float t4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < SK_MAX_WAVES; i++) t4[i & 3] += (uint32_t)i < nw ? ssq[min((uint32_t)i, nw - 1)] : 0.f;
+            const float rms = sqrtf(((t4[0] + t4[1]) + (t4[2] + t4[3])) / (float)p.K + p.eps);  // RMSNormShader.cs:143-146
+#pragma unroll
+            for (int q = 0; q < RPU; q++) a[q] = a[q] / rms;
+        }
+        if (begin) epilogue_prefetch<MODE>(p, unit, e0, e1, cs_tab);
+        epilogue<MODE>(p, unit, a[0], a[RPU - 1], e0, e1, pos_v);
+        if constexpr (MODE == GEMV_PLAIN) { best_v = a[0]; best_i = unit; }
+    }
+    if constexpr (MODE == GEMV_PLAIN) {
+        if (p.am.ticket != nullptr) argmax_fused_tail(best_v, best_i, p.am, am_lds);
+    }
+#ifdef NFAI_STAMPS
+    STAMP(4);  // rows reduced, epilogue stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(5);
+    STAMP_FLUSH(p.stamps, blockIdx.x * nw + w, 6);
+#endif
+}
+
+struct SkPlan { bool ok; int ch, rw; uint32_t nw, grid; };
+
+// shapes the split-K form takes: K = NW * CH chunks of one 16-byte load per lane, 2 <= NW <= 16, CH in {1, 2, 4}; everything else
+// (ragged K, the lm_head-sized streams, the side-stream prefetch) stays with k_gemv
+static SkPlan plan_gemv_sk(const GemvArgs &a, uint32_t NU, int epl, int rpu)
+{
+    SkPlan s{};
+    static const int env_on = getenv("NFAI_GEMV_SK") ? atoi(getenv("NFAI_GEMV_SK")) : 1;
+    static const int env_rw = getenv("NFAI_GEMV_SK_RW") ? atoi(getenv("NFAI_GEMV_SK_RW")) : 0;
+    // bit per GemvMode.  Default: PLAIN and RESIDUAL only.  Measured inside the model (3B fp16, tokens/s; profiles/round3_gemv_sk_model.txt):
+    // Wdown 672 against 670 with k_gemv (1B: 10.1 against 10.8 us per launch), but q|k|v 645 and gate|up 650 against 670 — with the
+    // RMSNorm'd modes every one of the 1000-2000 workgroups fetches x and the gains again (as many bytes through a CU's memory path as
+    // the weights of a q|k|v launch), which the stand-alone benchmark, with x hot in L2 and no epilogue, did not show.
+    static const int env_modes = getenv("NFAI_GEMV_SK_MODES") ? atoi(getenv("NFAI_GEMV_SK_MODES")) : 3;
+    if (!env_on || a.prefetch_only || !((env_modes >> (a.mode & 3)) & 1)) return s;
+    const uint32_t ce = 64u * epl;
+    if (a.K % ce) return s;
+    const uint32_t kc = a.K / ce;
+    for (int ch : {1, 2, 4}) {
+        if (kc % ch == 0 && kc / ch >= 2 && kc / ch <= (uint32_t)SK_MAX_WAVES) { s.ch = ch; s.nw = kc / ch; break; }
+    }
+    if (!s.ch) return s;
+    const uint64_t rows = (uint64_t)NU * rpu, bytes = rows * a.K * (epl == 8 ? 2 : 4);
+    if (bytes > (256ull << 20)) return s;  // the lm_head: a long stream is what the persistent form is good at (6.7 TB/s)
+    // rows per workgroup: 4 for the short matrices (more, smaller workgroups: 3B q|k|v 7.4 us against 7.7 / 9.1 with 8 / 16), 16
+    // loads per lane for the long ones (3B gate|up 17.3 against 18.2 with 4)
+    int rw = bytes >= (60ull << 20) ? 16 / s.ch : 4;
+    if (env_rw == 4 || env_rw == 8 || env_rw == 16) rw = env_rw;
+    while (rw * s.ch > 16) rw /= 2;
+    if (rw < 4) rw = 4;
+    if (rw * s.ch > 16) return s;
+    s.rw = rw;
+    s.grid = (NU + rw / rpu - 1) / (rw / rpu);
+    if (a.argmax_part && s.grid > ARGMAX_FUSED_MAX_BLOCKS) return s;  // the fused ArgMax keeps one partial per workgroup
+    s.ok = true;
+    return s;
+}
+
+template <int WT, int MODE, int CH, int RW>
+static hipError_t launch_sk(const GemvParams &p, const SkPlan &sp, hipStream_t s)
+{
+    if (p.gamma != nullptr) hipLaunchKernelGGL((k_gemv_sk<WT, MODE, CH, RW, true>), dim3(sp.grid), dim3(sp.nw * 64), 0, s, p);
+    else hipLaunchKernelGGL((k_gemv_sk<WT, MODE, CH, RW, false>), dim3(sp.grid), dim3(sp.nw * 64), 0, s, p);
+    return hipGetLastError();
+}
+
+template <int WT, int MODE>
+static hipError_t dispatch_sk(const GemvParams &p, const SkPlan &sp, hipStream_t s)
+{
+#define NFAI_SK(CH_, RW_) if (sp.ch == CH_ && sp.rw == RW_) return launch_sk<WT, MODE, CH_, RW_>(p, sp, s);
+    NFAI_SK(1, 4) NFAI_SK(1, 8) NFAI_SK(1, 16) NFAI_SK(2, 4) NFAI_SK(2, 8) NFAI_SK(4, 4)
+#undef NFAI_SK
+    return hipErrorInvalidValue;
+}
+
+template <int WT>
+static hipError_t dispatch_sk_mode(const GemvParams &p, const SkPlan &sp, int mode, hipStream_t s)
+{
+    switch (mode) {
+        case GEMV_PLAIN: return dispatch_sk<WT, GEMV_PLAIN>(p, sp, s);
+        case GEMV_RESIDUAL: return dispatch_sk<WT, GEMV_RESIDUAL>(p, sp, s);
+        case GEMV_QKV_ROPE: return dispatch_sk<WT, GEMV_QKV_ROPE>(p, sp, s);
+        case GEMV_GATEUP: return dispatch_sk<WT, GEMV_GATEUP>(p, sp, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 // ---- host side: shape checks and the (waves per block, units per wave step, K unroll) choice ----
@@ -462,13 +692,19 @@ static GemvPlan plan_gemv(uint32_t NU, uint32_t K, int epl, int rpu, uint32_t n_
     pl.upw = upw;
     pl.grid = grid;
     pl.block = wpb * 64;
-    pl.lds_bytes = (kc * ce + 16 + 48) * 4;
+    pl.lds_bytes = (kc * ce + 16 + 48 + BEGIN_CS_WORDS) * 4;  // x | reduction | fused ArgMax | cos/sin table of a token's first launch
     return pl;
 }
 
 template <int WT, int MODE, int UPW, int U, bool GUARD>
 static hipError_t launch_one(const GemvParams &p, const GemvPlan &pl, hipStream_t s)
 {
+    if constexpr (MODE == GEMV_QKV_ROPE) {
+        if (p.gamma != nullptr && p.begin.on) {  // the token's first launch: its own instantiation, nothing of it in the other 27
+            hipLaunchKernelGGL((k_gemv<WT, MODE, UPW, U, GUARD, true, true>), dim3(pl.grid), dim3(pl.block), pl.lds_bytes, s, p);
+            return hipGetLastError();
+        }
+    }
     if (p.gamma != nullptr)
         hipLaunchKernelGGL((k_gemv<WT, MODE, UPW, U, GUARD, true>), dim3(pl.grid), dim3(pl.block), pl.lds_bytes, s, p);
     else
@@ -554,12 +790,29 @@ hipError_t launch_gemv(const GemvArgs &a, hipStream_t s)
     p.pos = a.pos_dev;
     p.kv_f16 = a.kv_type == NFAI_F16;
     p.prefetch_only = a.prefetch_only ? 1u : 0u;
+    const SkPlan sp = plan_gemv_sk(a, p.NU, epl, rpu);
+    if (a.begin.on) {
+        if (a.mode != GEMV_QKV_ROPE || !a.gamma || !a.begin.freqs || !a.begin.cs_out || (a.begin.emb && (!a.begin.tok || !a.begin.x_out)) ||
+            a.begin.n_freq * 2 > BEGIN_CS_WORDS)
+            return hipErrorInvalidValue;  // (gemv_begin_ok() says which launches take it)
+        p.begin.on = 1; p.begin.emb = static_cast<const uint8_t *>(a.begin.emb); p.begin.emb_type = a.begin.emb_type; p.begin.emb_rows = a.begin.emb_rows;
+        p.begin.tok = a.begin.tok; p.begin.x_out = a.begin.x_out; p.begin.freqs = a.begin.freqs; p.begin.cs_out = a.begin.cs_out;
+        p.begin.n_freq = a.begin.n_freq; p.begin.epoch = a.begin.epoch;
+    }
     if (a.argmax_part) {
         if (a.mode != GEMV_PLAIN || !a.argmax_out) return hipErrorInvalidValue;
         p.am.part_v = static_cast<float *>(a.argmax_part);
         p.am.part_i = reinterpret_cast<uint32_t *>(p.am.part_v + ARGMAX_FUSED_MAX_BLOCKS);
         p.am.ticket = p.am.part_i + ARGMAX_FUSED_MAX_BLOCKS;
         p.am.out_idx = a.argmax_out; p.am.pos_inc = a.argmax_pos_inc; p.am.ring = a.argmax_ring; p.am.ring_len = a.argmax_ring_len;
+    }
+    if (sp.ok) {
+        p.KC = a.K / (64 * epl);
+        if (a.argmax_part && sp.grid > ARGMAX_FUSED_MAX_BLOCKS) return hipErrorInvalidValue;
+        static const char *sk_names[] = {"gemv_sk_plain", "gemv_sk_residual", "gemv_sk_qkv_rope", "gemv_sk_gateup"};
+        NFAI_STAMP_SET(p, sk_names[a.mode & 3], sp.grid, sp.nw * 64);
+        if (a.w_type == NFAI_F16) return dispatch_sk_mode<NFAI_F16>(p, sp, a.mode, s);
+        return dispatch_sk_mode<NFAI_F32>(p, sp, a.mode, s);
     }
     const GemvPlan pl = plan_gemv(p.NU, a.K, epl, rpu, a.n_cu, a.gamma != nullptr, a.mode);
     if (!pl.ok || (a.argmax_part && pl.grid > ARGMAX_FUSED_MAX_BLOCKS)) return hipErrorInvalidValue;
@@ -571,6 +824,15 @@ hipError_t launch_gemv(const GemvArgs &a, hipStream_t s)
     }
     if (a.w_type == NFAI_F16) return dispatch_mode<NFAI_F16>(p, pl, a.mode, s);
     return dispatch_mode<NFAI_F32>(p, pl, a.mode, s);
+}
+
+// does the first q|k|v launch described by `a` take the per-token prologue (GemvArgs::Begin)?  The fp16 / fp32 GEMV kernels and the
+// int8-MFMA K-quant kernel do; the VALU K-quant fall-back does not (the model then launches k_token_begin).
+bool gemv_begin_ok(const GemvArgs &a)
+{
+    if (a.mode != GEMV_QKV_ROPE || !a.gamma) return false;
+    if (a.w_type == NFAI_Q4_K_T16 || a.w_type == NFAI_Q6_K_T16 || a.w_type == NFAI_KQ_MIXED) return a.K % 256 == 0;
+    return a.w_type == NFAI_F16 || a.w_type == NFAI_F32;  // both forms of the fp16 / fp32 GEMV carry it
 }
 
 }  // namespace nfai

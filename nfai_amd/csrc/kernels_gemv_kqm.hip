@@ -121,8 +121,9 @@ __device__ __forceinline__ KqmPre kqm_preload(const KqmParams &p, uint32_t u, ui
         uint32_t seg, tile;
         kqm_unit<MODE>(p, u, 0, seg, tile);
         const uint32_t de = ((tile * 16 + r) % p.D) & ~1u;
-        q.cs = *reinterpret_cast<const GLOBAL_AS f32x2 *>((const GLOBAL_AS float *)p.rope_cs + min(de, p.rope_dims - 2));
         q.pos = *((const GLOBAL_AS uint32_t *)p.pos);
+        if (!p.begin.on)  // (first launch of a token: the epilogue takes cos/sin from the workgroup's own table in LDS, begin_bookkeeping)
+            q.cs = *reinterpret_cast<const GLOBAL_AS f32x2 *>((const GLOBAL_AS float *)p.rope_cs + min(de, p.rope_dims - 2));
     }
     return q;
 }
@@ -200,7 +201,13 @@ __global__ __launch_bounds__(1024) void k_gemv_kqt(const KqmParams p)
     for (int i = 0; i < BPW; i++) {
         const uint32_t bw = wid * BPW + i;
         const uint32_t kk = min(bw, p.NB - 1) * 256 + lane * 4;
-        const f32x4 v = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.x + kk);
+        f32x4 v;
+        if (MODE == GEMV_QKV_ROPE && NORM && p.begin.on && p.begin.emb) {  // block-uniform: the token's embedding row (first launch of a token)
+            v = embed_load4(p.begin.emb, p.begin.emb_type, p.begin.emb_rows, p.begin.tok[0], kk, p.K);
+            if (blockIdx.x == 0 && bw < p.NB) *reinterpret_cast<f32x4 *>(p.begin.x_out + kk) = v;  // the residual the later launches read
+        } else {
+            v = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.x + kk);
+        }
         xv[i] = bw < p.NB ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (NORM) gv[i] = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)p.gamma + kk);
     }
@@ -209,6 +216,10 @@ __global__ __launch_bounds__(1024) void k_gemv_kqt(const KqmParams p)
     // weights): without this fence hipcc's scheduler interleaves the loads below with them (measured: -2.5 % tokens/s)
     __builtin_amdgcn_sched_barrier(0);
     const KqmPre pre0 = kqm_preload<MODE>(p, min(blockIdx.x + wid * gridDim.x, p.NU - 1), lane);  // epilogue inputs of round 0
+    float *cs_lds = scal + 32 + 48;  // behind the fused ArgMax words
+    if constexpr (MODE == GEMV_QKV_ROPE && NORM) {
+        if (p.begin.on) begin_bookkeeping(p.begin, pre0.pos, cs_lds);
+    }
     // ---- weights of the first steps
     constexpr int NBUF = NS > 0 ? NS : 2;
     Regs buf[NBUF];
@@ -323,7 +334,15 @@ __global__ __launch_bounds__(1024) void k_gemv_kqt(const KqmParams p)
                 __syncthreads();
                 if (wid <= slot) {  // wave q finishes unit q of this round
                     const uint32_t uq = blockIdx.x + (ui - slot + wid) * gridDim.x;
-                    const KqmPre pre = ui == slot ? pre0 : kqm_preload<MODE>(p, uq, lane);
+                    KqmPre pre = ui == slot ? pre0 : kqm_preload<MODE>(p, uq, lane);
+                    if constexpr (MODE == GEMV_QKV_ROPE && NORM) {
+                        if (p.begin.on) {  // the table this workgroup tabulated before its first step (barrier above)
+                            uint32_t seg, tile;
+                            kqm_unit<MODE>(p, uq, 0, seg, tile);
+                            const uint32_t de = ((tile * 16 + (lane & 15)) % p.D) & ~1u;
+                            pre.cs = *reinterpret_cast<const f32x2 *>(cs_lds + min(de, p.rope_dims - 2));
+                        }
+                    }
                     float rms = 1.f;
                     if constexpr (NORM) {  // every wave's share of sum(x^2) is in LDS (written before its first step, barrier above)
                         float tss = 0.f;
@@ -671,6 +690,12 @@ hipError_t launch_gemv_kqm(const GemvArgs &a, hipStream_t s)
     p.rope_cs = a.rope_cs; p.rope_dims = a.rope_dims; p.D = a.D ? a.D : 2; p.pos = a.pos_dev;
     p.kv_f16 = a.kv_type == NFAI_F16;
     p.seg6 = a.seg6_mask;
+    if (a.begin.on) {
+        if (a.mode != GEMV_QKV_ROPE || !a.gamma || !a.begin.freqs || !a.begin.cs_out || (a.begin.emb && (!a.begin.tok || !a.begin.x_out))) return hipErrorInvalidValue;
+        p.begin.on = 1; p.begin.emb = static_cast<const uint8_t *>(a.begin.emb); p.begin.emb_type = a.begin.emb_type; p.begin.emb_rows = a.begin.emb_rows;
+        p.begin.tok = a.begin.tok; p.begin.x_out = a.begin.x_out; p.begin.freqs = a.begin.freqs; p.begin.cs_out = a.begin.cs_out;
+        p.begin.n_freq = a.begin.n_freq; p.begin.epoch = a.begin.epoch;
+    }
     if (a.argmax_part) {
         if (a.mode != GEMV_PLAIN || !a.argmax_out) return hipErrorInvalidValue;
         p.am.part_v = static_cast<float *>(a.argmax_part);
@@ -691,7 +716,7 @@ hipError_t launch_gemv_kqm(const GemvArgs &a, hipStream_t s)
     const int R = a.mode == GEMV_GATEUP ? 2 : 1;
     const size_t nlay = a.w_type == NFAI_KQ_MIXED ? 2 : 1;  // fragment layouts staged
     auto lds_bytes = [&](uint32_t ub) {
-        return nlay * ((size_t)nw * bpw * 1024 + (size_t)nw * bpw * 64) + (size_t)nw * bpw * 4 + (size_t)2 * ub * R * nw * 256 + 128 + 192;  // + 48 words of the fused ArgMax
+        return nlay * ((size_t)nw * bpw * 1024 + (size_t)nw * bpw * 64) + (size_t)nw * bpw * 4 + (size_t)2 * ub * R * nw * 256 + 128 + 192 + BEGIN_CS_WORDS * 4;  // + 48 words of the fused ArgMax + the cos/sin table of a token's first launch
     };
     while (p.UB > 1 && lds_bytes(p.UB) > 160 * 1024) p.UB--;  // very long K: fewer units per reduction round
     const size_t lds = lds_bytes(p.UB);

@@ -31,6 +31,7 @@ struct KqmParams {
     const uint32_t *pos;
     int kv_f16;
     ArgmaxFused am;            // GEMV_PLAIN: first index of the largest output, taken in this launch (am.ticket == nullptr: off)
+    BeginParams begin;         // GEMV_QKV_ROPE: the per-token prologue in this launch (begin.on == 0: off)
     NFAI_STAMP_PARAM
 };
 

@@ -309,35 +309,43 @@ GemvArgs gemv_base(Model *m, const Tensor &w, const float *x, uint32_t K)
 }
 
 // [RMSNorm + Wq, Wk, Wv + RoPE + KV write] of block L on the activation vector x (TransformerBlock.cs:129-141).
-int submit_qkv(Model *m, Layer &L, const float *x, Sched &sch)
+// One launch when q, k, v share an encoding; Q4_K_M files keep attn_v in Q6_K on some blocks: then the segments that differ get
+// their own launch (same kernel family, same epilogue).  qkv_launch: the launch that starts at segment `first` (-> `last`).
+GemvArgs qkv_launch(Model *m, Layer &L, const float *x, int first, int &last)
 {
     const nfai_llama_desc &d = m->d;
-    // One launch when q, k, v share an encoding; Q4_K_M files keep attn_v in Q6_K on some blocks:
-    // then the segments that differ get their own launch (same kernel family, same epilogue).
     const Tensor *seg[3] = {&L.wq, &L.wk, &L.wv};
     auto t16 = [](int ty) { return ty == NFAI_Q4_K_T16 || ty == NFAI_Q6_K_T16; };
+    last = first;
+    // segments of one encoding share a launch; so do T16 Q4_K and Q6_K segments (mixed kernel, kernels_gemv_kqm.hip)
+    while (last + 1 < 3 && (seg[last + 1]->type == seg[first]->type || (t16(seg[last + 1]->type) && t16(seg[first]->type)))) last++;
+    GemvArgs a = gemv_base(m, *seg[first], x, d.E);
+    for (int i = first; i <= last; i++) {
+        if (seg[i]->type != seg[first]->type) a.w_type = NFAI_KQ_MIXED;
+        if (seg[i]->type == NFAI_Q6_K_T16) a.seg6_mask |= 1u << i;
+    }
+    for (int i = 0; i < 3; i++) {
+        const bool in = i >= first && i <= last;
+        a.W[i] = in ? seg[i]->ptr : seg[first]->ptr;
+        a.seg_rows[i] = in ? (uint32_t)seg[i]->rows : 0;
+    }
+    a.gamma = static_cast<const float *>(L.attn_norm.ptr);
+    a.mode = GEMV_QKV_ROPE;
+    a.y = m->q;
+    a.kcache = L.kcache; a.vcache = L.vcache;
+    a.kv_type = m->kv_f16 ? NFAI_F16 : NFAI_F32;
+    a.kv_pos_stride = m->kv_pos_stride; a.kv_head_stride = m->kv_head_stride;
+    a.rope_cs = m->d_ropecs; a.rope_dims = d.rope_dims;
+    a.H = d.H; a.Hkv = d.Hkv; a.D = d.D;
+    return a;
+}
+
+int submit_qkv(Model *m, Layer &L, const float *x, Sched &sch, const GemvArgs::Begin *begin = nullptr)
+{
     for (int first = 0; first < 3;) {
-        int last = first;
-        // segments of one encoding share a launch; so do T16 Q4_K and Q6_K segments (mixed kernel, kernels_gemv_kqm.hip)
-        while (last + 1 < 3 && (seg[last + 1]->type == seg[first]->type || (t16(seg[last + 1]->type) && t16(seg[first]->type)))) last++;
-        GemvArgs a = gemv_base(m, *seg[first], x, d.E);
-        for (int i = first; i <= last; i++) {
-            if (seg[i]->type != seg[first]->type) a.w_type = NFAI_KQ_MIXED;
-            if (seg[i]->type == NFAI_Q6_K_T16) a.seg6_mask |= 1u << i;
-        }
-        for (int i = 0; i < 3; i++) {
-            const bool in = i >= first && i <= last;
-            a.W[i] = in ? seg[i]->ptr : seg[first]->ptr;
-            a.seg_rows[i] = in ? (uint32_t)seg[i]->rows : 0;
-        }
-        a.gamma = static_cast<const float *>(L.attn_norm.ptr);
-        a.mode = GEMV_QKV_ROPE;
-        a.y = m->q;
-        a.kcache = L.kcache; a.vcache = L.vcache;
-        a.kv_type = m->kv_f16 ? NFAI_F16 : NFAI_F32;
-        a.kv_pos_stride = m->kv_pos_stride; a.kv_head_stride = m->kv_head_stride;
-        a.rope_cs = m->d_ropecs; a.rope_dims = d.rope_dims;
-        a.H = d.H; a.Hkv = d.Hkv; a.D = d.D;
+        int last;
+        GemvArgs a = qkv_launch(m, L, x, first, last);
+        if (begin && first == 0) a.begin = *begin;  // the token's first launch also does the per-token prologue
         S_TRY(sch.submit(op_gemv(KC_QKV, a)));
         first = last + 1;
     }
@@ -365,10 +373,10 @@ AttnArgs attn_args(Model *m, Layer &L)
 int submit_attn(Model *m, Layer &L, Sched &sch) { return sch.submit(op_attn(KC_ATTN, attn_args(m, L))); }
 
 // One block, fused path (TransformerBlock.cs:127-184 in five launches + the attention merge).
-int block_fused(Model *m, Layer &L, Sched &sch)
+int block_fused(Model *m, Layer &L, Sched &sch, const GemvArgs::Begin *begin = nullptr)
 {
     const nfai_llama_desc &d = m->d;
-    S_TRY(submit_qkv(m, L, m->x, sch));
+    S_TRY(submit_qkv(m, L, m->x, sch, begin));
     {
         GemvArgs a = gemv_base(m, L.wo, m->att, d.H * d.D);
         a.mode = GEMV_RESIDUAL; a.res = m->x; a.y = m->h;
@@ -449,10 +457,33 @@ int enqueue_token(Model *m, bool with_head)
     Rec rec{m};
     const uint32_t nfreq = (d.rope_dims < d.D ? d.rope_dims : d.D) / 2;
     const bool emb_kq = is_kquant(m->token_embd.type);
-    if (m->first_stage && emb_kq)
-        K_TRY(KC_OTHER, launch_embed_kq(m->token_embd.ptr, m->token_embd.type, m->token_embd.rows, m->d_tok, m->x, d.E, s));
-    K_TRY(KC_OTHER, launch_token_begin(m->first_stage && !emb_kq ? m->token_embd.ptr : nullptr, m->token_embd.type, m->d_tok, m->x, d.E,
-                                       m->d_freqs, m->d_ropecs, nfreq, m->d_pos, s, m->d_epoch));
+    // The per-token prologue (embedding row -> x, cos/sin table of the position, hand-off epoch: TokenEmbedShader + what
+    // RoPEShader.cs:254-256 recomputes per element) rides on the first q|k|v launch of the token when that launch is one of
+    // the streaming GEMV kernels and the table is in a layout they read; otherwise it is its own launch.
+    GemvArgs::Begin begin;
+    {
+        auto streams = [](int ty) { return ty == NFAI_F16 || ty == NFAI_F32 || ty == NFAI_Q4_K_T16 || ty == NFAI_Q6_K_T16; };
+        const int et = m->token_embd.type;
+        static const bool env_off = getenv("NFAI_BEGIN_FUSED") && atoi(getenv("NFAI_BEGIN_FUSED")) == 0;
+        const bool engine_path = engine_ok(m) && m->eng_plans.size() == m->layers.size();
+        int last0;
+        const GemvArgs first_qkv = qkv_launch(m, m->layers[0], m->x, 0, last0);
+        begin.on = !env_off && !m->unfused && !engine_path && gemv_begin_ok(first_qkv) && nfreq * 2 <= 128 &&
+                   (!m->first_stage || streams(et)) && (!m->first_stage || (et != NFAI_Q4_K_T16 && et != NFAI_Q6_K_T16) || d.E % 256 == 0);
+        if (begin.on) {
+            if (m->first_stage) {
+                begin.emb = m->token_embd.ptr; begin.emb_type = et; begin.emb_rows = m->token_embd.rows;
+                begin.tok = m->d_tok; begin.x_out = m->x;
+            }
+            begin.freqs = m->d_freqs; begin.cs_out = m->d_ropecs; begin.n_freq = nfreq; begin.epoch = m->d_epoch;
+        }
+    }
+    if (!begin.on) {
+        if (m->first_stage && emb_kq)
+            K_TRY(KC_OTHER, launch_embed_kq(m->token_embd.ptr, m->token_embd.type, m->token_embd.rows, m->d_tok, m->x, d.E, s));
+        K_TRY(KC_OTHER, launch_token_begin(m->first_stage && !emb_kq ? m->token_embd.ptr : nullptr, m->token_embd.type, m->d_tok, m->x, d.E,
+                                           m->d_freqs, m->d_ropecs, nfreq, m->d_pos, s, m->d_epoch));
+    }
     if (m->unfused) {
         for (Layer &L : m->layers) {
             int rc = block_unfused(m, L, rec);
@@ -486,7 +517,7 @@ int enqueue_token(Model *m, bool with_head)
         }
     } else {
         for (Layer &L : m->layers) {
-            int rc = block_fused(m, L, sch);
+            int rc = block_fused(m, L, sch, (begin.on && &L == &m->layers[0]) ? &begin : nullptr);
             if (rc) return rc;
         }
     }

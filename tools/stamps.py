@@ -158,6 +158,10 @@ def main():
                 d.setdefault("merge_and_store", []).extend(mg[:, 7] - mg[:, 5])
         else:
             d["issued"].extend(t[:, 1] - t[:, 0])
+            if (t[:, 6] > 0).any():  # fp16 GEMV with RMSNorm: own x arrived / workgroup sum known
+                ok_ = t[:, 6] > 0
+                d.setdefault("own_x_arrived", []).extend(t[ok_, 6] - t[ok_, 0])
+                d.setdefault("norm_sum_known", []).extend(t[ok_, 7] - t[ok_, 0])
             d["x_ready"].extend(t[:, 2] - t[:, 0])
             d["first_consumed"].extend(t[:, 3] - t[:, 0])
             d["stream"].extend(t[:, 4] - t[:, 3])
