@@ -707,7 +707,10 @@ hipError_t launch_gemv_kqm(const GemvArgs &a, hipStream_t s)
     int bpw = p.NB <= 16 ? 1 : (p.NB <= 32 ? 2 : (p.NB <= 64 ? 4 : 8));  // K <= 32768 (Llama-70B: ffn length 28672)
     if ((env_bpw == 2 || env_bpw == 4) && env_bpw > bpw && p.NB % env_bpw == 0) bpw = env_bpw;
     const uint32_t nw = (p.NB + bpw - 1) / bpw;
-    static const int env_bpc = getenv("NFAI_KQM_BPC") ? atoi(getenv("NFAI_KQM_BPC")) : 1;  // sweep knobs
+    // workgroups per CU.  One, except for q|k|v: its 320 tiles (3B) on 256 single workgroups leave 64 of them two tiles in a row; as 320
+    // workgroups, two of them share 64 CUs instead (3B Q4_K_M: 8.97 against 9.19 us per launch; the lm_head loses 3 us with two)
+    static const int env_bpc_all = getenv("NFAI_KQM_BPC") ? atoi(getenv("NFAI_KQM_BPC")) : 0;  // sweep knobs
+    const int env_bpc = env_bpc_all ? env_bpc_all : (a.mode == GEMV_QKV_ROPE ? 2 : 1);
     static const int env_ub = getenv("NFAI_KQM_UB") ? atoi(getenv("NFAI_KQM_UB")) : 4;
     const uint32_t grid = min(p.NU, a.n_cu * (uint32_t)max(1, min(env_bpc, 8)));
     if (a.argmax_part && grid > ARGMAX_FUSED_MAX_BLOCKS) return hipErrorInvalidValue;

@@ -677,7 +677,7 @@ NFAI_API int32_t nfai_hip_llama_create(nfai_ctx_t ch, const nfai_llama_desc *des
     {
         const char *env = getenv("NFAI_PREFETCH");
         m->prefetch = env ? (env[0] == '1') : ((d.flags & NFAI_LLAMA_PREFETCH) != 0);
-        if (m->prefetch) HIP_TRY(hipStreamCreateWithFlags(&m->s2, hipStreamNonBlocking));
+        if (m->prefetch || d.max_batch > 0) HIP_TRY(hipStreamCreateWithFlags(&m->s2, hipStreamNonBlocking));  // (the prefill reads weights ahead on it)
     }
     {
         const char *env = getenv("NFAI_ENGINE");
@@ -1103,6 +1103,35 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
     // operand and ~80 VALU operations of dequantisation per 16 weights cost more than the widening pass saves (measured).
     static const bool widen = !(getenv("NFAI_PREFILL_FUSED") && atoi(getenv("NFAI_PREFILL_FUSED")));
     const uint32_t QKV = HD + 2 * KD;
+    // NFAI_PREFILL_READAHEAD=1 (off by default): read-ahead of the next GEMM's fp16 weights on the side stream (kernels_prefill.hip:
+    // k_read_ahead), issued when the GEMM in front of it starts, so at most two matrices' worth of bytes (<= 150 MB at 3B) compete for
+    // the 256 MB Infinity Cache.  Built because the projections run 15-40 % faster on cache-resident weights (tools/gemm_bench.py);
+    // measured in the prefill it LOSES: 6.39-6.44 ms against 5.93 ms per 512 tokens at 3B — beside a GEMM that lives on L2 hits the
+    // read-ahead's own HBM stream costs more than the first-use latency it removes (as the side-stream widening did in round 2).
+    static const bool read_ahead = getenv("NFAI_PREFILL_READAHEAD") && atoi(getenv("NFAI_PREFILL_READAHEAD")) == 1;
+    size_t ra_ev = 0;
+    bool ra_used = false;
+    auto ahead = [&](std::initializer_list<const Tensor *> ts) -> int {
+        if (!read_ahead || !m->s2) return NFAI_OK;
+        bool any = false;
+        for (const Tensor *t : ts) any = any || (t->ptr && t->type == NFAI_F16);
+        if (!any) return NFAI_OK;
+        if (ra_ev >= m->pf_events.size()) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            m->pf_events.push_back(e);
+        }
+        hipEvent_t ev = m->pf_events[ra_ev++];
+        HIP_TRY(hipEventRecord(ev, s));              // everything enqueued so far: the read-ahead starts with the GEMM in front of it
+        HIP_TRY(hipStreamWaitEvent(m->s2, ev, 0));
+        for (const Tensor *t : ts)
+            if (t->ptr && t->type == NFAI_F16) {
+                hipError_t e = launch_read_ahead(t->ptr, t->rows * t->cols * 2, (uint32_t)m->ctx->prop.multiProcessorCount, m->s2);
+                if (e != hipSuccess) return fail(NFAI_ERR_HIP, "prefill: read-ahead launch failed: %s", hipGetErrorString(e));
+            }
+        ra_used = true;
+        return NFAI_OK;
+    };
     HIP_TRY(hipMemcpyAsync(w.toks, tokens, (size_t)T * 4, hipMemcpyHostToDevice, s));
     if (is_kquant(m->token_embd.type))
         P_TRY(launch_embed_rows_kqt(m->token_embd.ptr, m->token_embd.type, m->token_embd.rows, w.toks, w.X, T, d.E, s));
@@ -1123,6 +1152,7 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
             }
         }
         P_TRY(launch_rmsnorm_rows(w.X, static_cast<const float *>(L.attn_norm.ptr), w.XN, T, d.E, d.eps, s));
+        S_TRY(ahead({&L.wo}));                                                           // while q | k | v computes
         P_TRY(gemm(w.XN, d.E, L.wq, &L.wk, &L.wv, w.Q, nullptr, QKV, d.E));              // q | k | v in one launch
         P_TRY(launch_rope_store_rows(w.Q, w.Q + HD, w.Q + HD + KD, w.QH, L.kcache, L.vcache, kvf16, m->kv_pos_stride, m->kv_head_stride,
                                      m->d_freqs, d.rope_dims, d.H, d.Hkv, d.D, pos0, T, QKV, w.KH, w.VT, Spad, s));
@@ -1154,8 +1184,10 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
                 P_TRY(launch_gemm_f16(g, s));
             }
         }
+        S_TRY(ahead({&L.wgate, &L.wup}));                                                // while Wo computes
         P_TRY(gemm(w.XN, HD, L.wo, nullptr, nullptr, w.H1, w.X, d.E, HD));                 // + residual (TransformerBlock.cs:153-158)
         P_TRY(launch_rmsnorm_rows(w.H1, static_cast<const float *>(L.ffn_norm.ptr), w.XN, T, d.E, d.eps, s));
+        S_TRY(ahead({&L.wdown}));                                                        // while gate | up computes
         {   // gate | up in one launch, act = up * silu(gate) formed in the GEMM epilogue (fp16 [T][F])
             GemmArgs g;
             g.A = w.XN; g.lda = d.E; g.B = L.wgate.ptr; g.B1 = L.wup.ptr; g.n0 = d.F; g.ldb = d.E;
@@ -1169,7 +1201,21 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
                 P_TRY(launch_gemm_kq(g, s));
             }
         }
+        if (&Lq != &m->layers.back()) {                                                  // while Wdown computes: the next block's q, k, v
+            const Layer &N = *(&Lq + 1);
+            S_TRY(ahead({&N.wq, &N.wk, &N.wv}));
+        }
         P_TRY(gemm(w.ACT, d.F, L.wdown, nullptr, nullptr, w.X, w.H1, d.E, d.F));           // + residual (:176-181)
+    }
+    if (ra_used) {  // the side stream only reads weights; the join keeps destroy / set_tensor from racing with it
+        if (ra_ev >= m->pf_events.size()) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            m->pf_events.push_back(e);
+        }
+        hipEvent_t ev = m->pf_events[ra_ev++];
+        HIP_TRY(hipEventRecord(ev, m->s2));
+        HIP_TRY(hipStreamWaitEvent(s, ev, 0));
     }
 #undef P_TRY
     // the last token's hidden state continues on the M = 1 path (output norm + lm_head + argmax)
