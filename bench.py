@@ -305,7 +305,7 @@ def run_single(args):
     traffic, traffic_source = None, None
     if args.model == "llama-3.2-3b":
         tag = "" if args.quant == "f16" else "_q4km"
-        for rnd in ("round2", "round1"):  # newest committed PMC summary of this workload
+        for rnd in ("round3", "round2", "round1"):  # newest committed PMC summary of this workload
             f = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic{tag}.json")
             try:
                 pmc = json.load(open(f))

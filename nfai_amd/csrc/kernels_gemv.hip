@@ -278,11 +278,6 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
         for (int r = 0; r < R; r++) issue_loads<WT, U, GUARD>(buf[r], rows[r], iw.cg * U, lane, p.K);
         iw.next(cpg);
     };
-#ifdef GEMV_X_BARRIER
-    // every wave's activation requests enter the CU's in-order memory queue before any wave's weight requests (raw s_barrier: no
-    // wait for memory)
-    __builtin_amdgcn_s_barrier();
-#endif
     // unconditional (row indices are clamped to valid rows): a branch around the issue would make the
     // compiler's vmcnt bookkeeping take the worst path and wait for the weights before using x
     issue(bufA);

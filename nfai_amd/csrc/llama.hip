@@ -1285,8 +1285,13 @@ NFAI_API int32_t nfai_hip_llama_prefill(nfai_model_t h, const uint32_t *tokens, 
         GemvArgs a = gemv_base(m, head, m->x, m->d.E);
         a.gamma = static_cast<const float *>(m->output_norm.ptr);
         a.y = m->logits;
+        const bool am_fused = head.type == NFAI_F16 || head.type == NFAI_F32 || head.type == NFAI_Q4_K_T16 || head.type == NFAI_Q6_K_T16;
+        if (am_fused) {  // ArgMax in the lm_head launch, as in a decode step; no bookkeeping: the position was set above
+            a.argmax_part = static_cast<char *>(m->d_argmax_part) + 4096;
+            a.argmax_out = m->d_tok;
+        }
         K_TRY(KC_LMHEAD, launch_gemv(a, s));
-        K_TRY(KC_OTHER, launch_argmax(m->logits, m->d.V, m->d_tok, m->d_argmax_part, nullptr, nullptr, 0, s));
+        if (!am_fused) K_TRY(KC_OTHER, launch_argmax(m->logits, m->d.V, m->d_tok, m->d_argmax_part, nullptr, nullptr, 0, s));
     }
     if (logits_last_host) HIP_TRY(hipMemcpyAsync(logits_last_host, m->logits, (size_t)m->d.V * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));

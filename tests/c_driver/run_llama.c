@@ -32,6 +32,9 @@ void orc_llama_set_layer(orc_llama *m, uint32_t l, const float *attn_norm, const
                          const float *ffn_norm, const void *wgate, const void *wup, const void *wdown);
 int orc_llama_step(orc_llama *m, uint32_t tok, float *logits);
 uint32_t orc_argmax(const float *v, uint32_t n);
+void orc_llama_reset(orc_llama *m);
+uint32_t orc_topp(const float *values, uint32_t n, float temperature, float topP, uint32_t topK, float rand, uint32_t *ids_out, float *probs_out,
+                  uint32_t *n_kept_out);
 uint16_t orc_float_to_half(float f);
 
 #define CHECK(call)                                                                         \
@@ -153,6 +156,31 @@ int main(void)
     for (uint32_t k = 0; k < n_gen; k++)
         if (dev_tokens[k] != tokens[k]) { fprintf(stderr, "device greedy loop differs at %u: %u vs %u\n", k, dev_tokens[k], tokens[k]); return 1; }
     printf("device greedy loop: %u tokens identical\n", n_gen);
+
+    /* the reference's DEFAULT sampler (LlamaModel.cs:128-130: SamplingUtils.TopP on the logits it reads back): the candidates come
+     * from the device (nfai_hip_llama_decode_topk), the nucleus cut and the draw are the host's — SamplingUtils.cs:14-31 restated */
+    CHECK(nfai_hip_llama_reset(model));
+    orc_llama_reset(ref);
+    {
+        uint32_t tok = prompt[0], ids[40], ids_ref[40], kept = 0, mism = 0;
+        float probs[40], probs_ref[40];
+        const float rands[6] = {0.03f, 0.31f, 0.5f, 0.77f, 0.94f, 0.999f};
+        for (uint32_t i = 0; i < 6; i++) {
+            CHECK(nfai_hip_llama_decode_topk(model, tok, 0.5f, 40, ids, probs));
+            if (orc_llama_step(ref, tok, lr) != 0) return 2;
+            const uint32_t want = orc_topp(lr, V, 0.5f, 0.95f, 40, rands[i], ids_ref, probs_ref, &kept);
+            float cumulative = 0.f, total = 0.f, running = 0.f;   /* SamplingUtils.cs:14-31 on the device's candidates */
+            uint32_t n = 0, got = 0;
+            for (; n < 40;) { cumulative += probs[n]; n++; if (cumulative >= 0.95f) break; }
+            { double t = 0.0; for (uint32_t k = 0; k < n; k++) t += probs[k]; total = (float)t; }
+            got = ids[n - 1];
+            for (uint32_t k = 0; k < n; k++) { running += probs[k] / total; if (rands[i] < running) { got = ids[k]; break; } }
+            if (ids[0] != ids_ref[0] || fabsf(probs[0] - probs_ref[0]) > 2e-4f * probs_ref[0] || got != want) mism++;
+            tok = want;
+        }
+        printf("sampling path: 6 steps of decode_topk + the host half of TopP, mismatches against the oracle = %u\n", mism);
+        if (mism) return 1;
+    }
 
     /* KV capacity is enforced (the reference writes out of bounds, MatrixMultiplyShader.cs:248-252) */
     CHECK(nfai_hip_llama_set_pos(model, C));

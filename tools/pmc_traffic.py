@@ -3,8 +3,8 @@
 (--pmc FETCH_SIZE, --pmc WRITE_SIZE; with --kernel-trace only), hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (on gfx950
 FETCH_SIZE reports half of a 16 B/lane coalesced stream; WRITE_SIZE is exact).
 
-    tools/pmc_traffic.py f16     -> gpurun_out/round2_pmc_traffic.json       (copied to profiles/; bench.py reads `traffic` from it)
-    tools/pmc_traffic.py q4_k_m  -> gpurun_out/round2_pmc_traffic_q4km.json
+    tools/pmc_traffic.py f16     -> gpurun_out/round3_pmc_traffic.json       (copied to profiles/; bench.py reads `traffic` from it)
+    tools/pmc_traffic.py q4_k_m  -> gpurun_out/round3_pmc_traffic_q4km.json
 
 The profiled command is bench.py at ITS OWN context (512 prompt tokens through the MFMA prefill, then decode steps at
 positions 512...), so the counters belong to the launches the benchmark times.  Runs on the GPU box."""
@@ -18,7 +18,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 quant = sys.argv[1] if len(sys.argv) > 1 else "f16"
-out_json = os.path.join(ROOT, "gpurun_out", "round2_pmc_traffic.json" if quant == "f16" else "round2_pmc_traffic_q4km.json")
+out_json = os.path.join(ROOT, "gpurun_out", "round3_pmc_traffic.json" if quant == "f16" else "round3_pmc_traffic_q4km.json")
 bench = ["python3", os.path.join(ROOT, "bench.py"), "--quant", quant, "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--profile-steps", "0"]
 vals = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -43,7 +43,10 @@ V = 128256
 
 def algorithmic_bytes(name):
     import re
-    m = re.match(r"nfai::k_gemv<(\d+), (\d+), (\d+), (\d+), (\w+), (\w+)>", name)
+    sk = re.match(r"nfai::k_gemv_sk<(\d+), (\d+), (\d+), (\d+), (\w+)>", name)  # split-K form <WT, MODE, CH, RW, NORM>
+    if sk and sk.group(1) == "1" and int(sk.group(2)) == 1:
+        return E * F * 2   # the only fp16 RESIDUAL launch of its own at 3B is Wdown (Wo rides in k_attn_wo); K = 8192 = 16 waves x 1 chunk
+    m = re.match(r"nfai::k_gemv<(\d+), (\d+), (\d+), (\d+), (\w+), (\w+)(?:, \w+)?>", name)
     if m and m.group(1) == "1":
         mode, u = int(m.group(2)), int(m.group(4))
         if mode == 3:
