@@ -548,29 +548,35 @@ template <int N> __device__ __forceinline__ void wait_vmcnt()
 // only A, waves 2-3 only B, each with its own counted wait; the barrier joins them.  (In a prefill the 192-workgroup
 // projections were found waiting on HBM latency, not on L2 / LDS / MFMA: profiles/round2_prefill_pmc.json — 1 TB/s on the
 // memory side, MFMA 22 % busy.)
-template <int BM, int BN, int WM, int WN, int EPI, int NST, int BK = 64, bool PIPE = false, int NSTB = NST>
-__global__ __launch_bounds__(256) void k_gemm_f16_glds(const GemmParams p)
+// KS = 2: two groups of WM x WN waves share the tile; group g multiplies the k-steps s with s % KS == g of every K tile, and the
+// groups' accumulators meet in LDS after the K loop (the narrow projections have one workgroup per CU: a second wave per SIMD
+// fills the first one's waits for LDS reads, its barrier and its LDS-DMA issue).  WM * WN = 8, KS = 1: eight waves, one tile each.
+template <int BM, int BN, int WM, int WN, int EPI, int NST, int BK = 64, bool PIPE = false, int NSTB = NST, int KS = 1>
+__global__ __launch_bounds__(WM *WN *KS * 64) void k_gemm_f16_glds(const GemmParams p)
 {
     static_assert(NSTB >= NST, "the weight ring is at least as deep as the activation ring");
-    static_assert(WM * WN == 4, "four waves");
+    constexpr int NWT = WM * WN, NW = NWT * KS;  // waves that own a tile position; waves of the workgroup
+    static_assert(NW == 4 || NW == 8 || NW == 16, "four, eight or sixteen waves");
     constexpr bool ROLES = NSTB != NST;
+    static_assert(!ROLES || NW == 4, "operand roles are written for four waves");
+    static_assert(KS == 1 || (!PIPE && (BK / 32) % KS == 0), "k-steps of a tile are dealt to the wave groups");
     constexpr int CH = BK / 8, RPI = 64 / CH, TM = BM / WM / 16, TN = BN / WN / 16;  // RPI = tile rows per LDS-DMA instruction
     // LDS-DMA instructions per wave and tile.  Without roles the tile's BM / RPI + BN / RPI instructions are dealt to the four
     // waves round-robin; when BN / RPI is not a multiple of four (BN = 80, 48: tile widths that give exactly 256 workgroups on the
     // 5120- and 3072-column projections at 512 rows) the last B instruction exists only for the first waves (b_last).  With roles
     // a wave pair shares one operand: instruction i of pair member w covers LDS rows (i * 2 + w) * RPI ...
     constexpr int NAI = BM / RPI, NBI = BN / RPI;
-    constexpr int AG = ROLES ? NAI / 2 : NAI / 4, BG = ROLES ? NBI / 2 : (NBI + 3) / 4;
-    constexpr int DEAL = ROLES ? 2 : 4;
-    constexpr bool B_EVEN = ROLES || NBI % 4 == 0;
-    static_assert(BM % (RPI * 4) == 0 && BN % RPI == 0 && (!ROLES || NBI % 2 == 0), "tile rows per LDS-DMA instruction");
+    constexpr int DEAL = ROLES ? 2 : NW;
+    constexpr int AG = NAI / DEAL, BG = ROLES ? NBI / 2 : (NBI + NW - 1) / NW;
+    constexpr bool B_EVEN = ROLES || NBI % NW == 0;
+    static_assert(BM % (RPI * DEAL) == 0 && BN % RPI == 0 && (!ROLES || NBI % 2 == 0), "tile rows per LDS-DMA instruction");
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, B_BASE = NST * A_BYTES;  // LDS: NST A stages, then NSTB B stages
     static_assert(EPI != EPI_SILU || BN / WN == 64, "SiLU epilogue pairs columns inside a 64-wide wave slice");
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     typedef __attribute__((address_space(3))) uint8_t lds_u8;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WN, wn = wave % WN;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), kg = wave / NWT, wm = (wave % NWT) / WN, wn = wave % WN;
     const uint32_t tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
     uint32_t mt_i, nt_i;
     {
@@ -590,7 +596,7 @@ __global__ __launch_bounds__(256) void k_gemm_f16_glds(const GemmParams p)
     const GLOBAL_AS uint8_t *Bg = (const GLOBAL_AS uint8_t *)p.B[0], *Bu = (const GLOBAL_AS uint8_t *)p.B[1];
     const bool role_a = !ROLES || wave < 2, role_b = !ROLES || wave >= 2;  // wave-uniform
     const uint32_t dw = ROLES ? (wave & 1) : wave;                         // this wave's place in the deal
-    const bool b_last = B_EVEN || (uint32_t)(BG - 1) * 4 + wave < (uint32_t)NBI;
+    const bool b_last = B_EVEN || (uint32_t)(BG - 1) * NW + wave < (uint32_t)NBI;
 
     // per-lane source rows: lane = (row % RPI) * CH + c'
     const uint32_t lrow = lane / CH, lc = lane % CH;
@@ -722,9 +728,9 @@ __global__ __launch_bounds__(256) void k_gemm_f16_glds(const GemmParams p)
             }
         } else {
 #pragma unroll
-            for (int ks = 0; ks < KSTEPS; ks++) {
+            for (int ks = 0; ks < KSTEPS / KS; ks++) {
                 f16x8 af[TM], bf[TN];
-                load_frags(ks, af, bf);
+                load_frags(ks * KS + (KS > 1 ? (int)kg : 0), af, bf);
 #pragma unroll
                 for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -738,23 +744,47 @@ __global__ __launch_bounds__(256) void k_gemm_f16_glds(const GemmParams p)
     }
     GEMM_TICK(c_mul);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus DMAs of the last iterations must not outlive the workgroup's LDS
+    if constexpr (KS > 1) {
+        // every wave's DMAs have landed and every wave is past its last fragment read: the stages are free for the groups' sums
+        static_assert((KS - 1) * BM * BN * 4 <= (NST * BM + NSTB * BN) * BK * 2, "the other groups' accumulators fit the stages");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        constexpr uint32_t SLAB = NWT * TM * TN * 64;  // f32x4 words per group
+        f32x4 *slab = reinterpret_cast<f32x4 *>(lds) + (size_t)(wave % NWT) * TM * TN * 64 + lane;
+        if (kg != 0) {
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) slab[(kg - 1) * SLAB + (i * TN + j) * 64] = acc[i][j];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kg != 0) return;
+#pragma unroll
+        for (int g2 = 1; g2 < KS; g2++)  // fixed order: group 0 + group 1 + ...
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j] += slab[(g2 - 1) * SLAB + (i * TN + j) * 64];
+    }
     gemm_store<BM, BN, WM, WN, EPI, TM, TN>(acc, p, m0, n0, wm, wn, lane, batch);
 #ifdef NFAI_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GEMM_TICK(c_issue);  // epilogue counted with the issue bucket's neighbour below
     _st.t[0] = c_start; _st.t[1] = c_wait; _st.t[2] = c_bar; _st.t[3] = c_issue; _st.t[4] = c_mul; _st.t[5] = c1; _st.t[6] = KT;
-    STAMP_FLUSH(p.stamps, blockIdx.x * 4 + wave, 7);
+    STAMP_FLUSH(p.stamps, blockIdx.x * NW + wave, 7);
 #endif
 #undef GEMM_TICK
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int NST, int BK = 64, bool PIPE = false, int NSTB = NST>
+template <int BM, int BN, int WM, int WN, int EPI, int NST, int BK = 64, bool PIPE = false, int NSTB = NST, int KS = 1>
 static hipError_t gemm_launch_glds(const GemmParams &p, uint32_t batch, hipStream_t s)
 {
+    constexpr int NW = WM * WN * KS;
     constexpr int LDS = (NST * BM + NSTB * BN) * BK * 2;
     static_assert(LDS <= 160 * 1024, "LDS of one CU");
     if (p.K % BK) return hipErrorInvalidValue;
-    auto kern = k_gemm_f16_glds<BM, BN, WM, WN, EPI, NST, BK, PIPE, NSTB>;
+    auto kern = k_gemm_f16_glds<BM, BN, WM, WN, EPI, NST, BK, PIPE, NSTB, KS>;
     static bool attr_set = false;
     if (LDS > 64 * 1024 && !attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -763,8 +793,8 @@ static hipError_t gemm_launch_glds(const GemmParams &p, uint32_t batch, hipStrea
     }
     const uint32_t tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
     GemmParams pp = p;
-    NFAI_STAMP_SET(pp, "gemm_glds", tiles, 256);
-    hipLaunchKernelGGL(kern, dim3(tiles, batch, 1), dim3(256), LDS, s, pp);
+    NFAI_STAMP_SET(pp, "gemm_glds", tiles, NW * 64);
+    hipLaunchKernelGGL(kern, dim3(tiles, batch, 1), dim3(NW * 64), LDS, s, pp);
     return hipGetLastError();
 }
 
@@ -790,8 +820,8 @@ template <int EPI>
 static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int variant, hipStream_t s)
 {
     if (variant) {  // explicit configuration (tests, tools)
-        if (((variant >= 2 && variant <= 4) || variant == 11 || variant == 18 || variant == 19) && p.N % 128 != 0) return hipErrorInvalidValue;
-        if (variant >= 12 && variant <= 15 && (p.seg_end[0] % 16 || p.seg_end[1] % 16)) return hipErrorInvalidValue;
+        if (((variant >= 2 && variant <= 4) || variant == 11 || variant == 18 || variant == 19 || (variant >= 21 && variant <= 25)) && p.N % 128 != 0) return hipErrorInvalidValue;
+        if (((variant >= 12 && variant <= 15) || (variant >= 27 && variant <= 34) || variant == 36 || variant == 37 || variant == 40 || variant == 41) && (p.seg_end[0] % 16 || p.seg_end[1] % 16)) return hipErrorInvalidValue;
         switch (variant) {
             case 1: return gemm_launch<128, 64, 4, 1, 64, EPI>(p, batch, s);
             case 2: return gemm_launch<128, 128, 2, 2, 64, EPI>(p, batch, s);
@@ -813,6 +843,28 @@ static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int va
             case 18: return gemm_launch_glds<128, 128, 2, 2, EPI, 3, 64, false, 4>(p, batch, s);   // 128 x 128: weights 3 tiles ahead (112 KB)
             case 19: return gemm_launch_glds<128, 128, 2, 2, EPI, 3, 64, false, 6>(p, batch, s);   // 5 tiles ahead (144 KB)
             case 20: if constexpr (EPI != EPI_SILU) return p.N % 80 ? hipErrorInvalidValue : gemm_launch_glds<128, 80, 4, 1, EPI, 3, 64, false, 6>(p, batch, s); else break;
+            case 21: return gemm_launch_glds<256, 128, 2, 2, EPI, 2>(p, batch, s);                             // four waves of 128 x 64 (96 KB)
+            case 22: return gemm_launch_glds<256, 128, 2, 2, EPI, 3>(p, batch, s);                             // (144 KB)
+            case 23: return gemm_launch_glds<256, 128, 4, 2, EPI, 2>(p, batch, s);                             // eight waves of 64 x 64
+            case 24: return gemm_launch_glds<256, 128, 4, 2, EPI, 3>(p, batch, s);
+            case 25: return gemm_launch_glds<128, 128, 2, 2, EPI, 3, 64, false, 3, 2>(p, batch, s);            // two wave groups split the k-steps
+            case 26: return gemm_launch_glds<128, 64, 4, 1, EPI, 3, 64, false, 3, 2>(p, batch, s);
+            case 27: if constexpr (EPI != EPI_SILU) return p.N % 80 ? hipErrorInvalidValue : gemm_launch_glds<128, 80, 4, 1, EPI, 3, 64, false, 3, 2>(p, batch, s); else break;
+            case 28: if constexpr (EPI != EPI_SILU) return p.N % 48 ? hipErrorInvalidValue : gemm_launch_glds<128, 48, 4, 1, EPI, 3, 64, false, 3, 2>(p, batch, s); else break;
+            case 29: if constexpr (EPI != EPI_SILU) return p.N % 48 ? hipErrorInvalidValue : gemm_launch_glds<128, 48, 4, 1, EPI, 4, 64, false, 4, 2>(p, batch, s); else break;
+            case 31: if constexpr (EPI != EPI_SILU) return p.N % 48 ? hipErrorInvalidValue : gemm_launch_glds<128, 48, 4, 1, EPI, 5, 64, false, 5, 2>(p, batch, s); else break;
+            case 32: if constexpr (EPI != EPI_SILU) return p.N % 48 || p.K % 128 ? hipErrorInvalidValue : gemm_launch_glds<128, 48, 4, 1, EPI, 3, 128, false, 3, 2>(p, batch, s); else break;
+            case 33: if constexpr (EPI != EPI_SILU) return p.N % 48 || p.K % 128 ? hipErrorInvalidValue : gemm_launch_glds<128, 48, 4, 1, EPI, 3, 128, false, 3, 4>(p, batch, s); else break;
+            case 34: if constexpr (EPI != EPI_SILU) return p.N % 80 ? hipErrorInvalidValue : gemm_launch_glds<128, 80, 4, 1, EPI, 4, 64, false, 4, 2>(p, batch, s); else break;
+            case 35: return p.N % 128 ? hipErrorInvalidValue : gemm_launch_glds<256, 128, 4, 2, EPI, 3, 64, false, 3, 2>(p, batch, s);
+            case 36: if constexpr (EPI != EPI_SILU) return p.N % 48 ? hipErrorInvalidValue : gemm_launch_glds<128, 48, 4, 1, EPI, 6, 64, false, 6, 2>(p, batch, s); else break;
+            case 37: if constexpr (EPI != EPI_SILU) return p.N % 80 ? hipErrorInvalidValue : gemm_launch_glds<128, 80, 4, 1, EPI, 5, 64, false, 5, 2>(p, batch, s); else break;
+            case 38: return p.N % 128 ? hipErrorInvalidValue : gemm_launch_glds<128, 128, 2, 2, EPI, 4, 64, false, 4, 2>(p, batch, s);
+            case 39: return p.K % 128 ? hipErrorInvalidValue : gemm_launch_glds<128, 64, 4, 1, EPI, 3, 128, false, 3, 2>(p, batch, s);
+            case 40: if constexpr (EPI != EPI_SILU) return p.N % 80 || p.K % 128 ? hipErrorInvalidValue : gemm_launch_glds<128, 80, 4, 1, EPI, 3, 128, false, 3, 2>(p, batch, s); else break;
+            case 41: if constexpr (EPI != EPI_SILU) return p.N % 96 ? hipErrorInvalidValue : gemm_launch_glds<128, 96, 4, 1, EPI, 4, 64, false, 4, 2>(p, batch, s); else break;
+            case 42: return gemm_launch_glds<128, 64, 4, 1, EPI, 4, 64, false, 4, 2>(p, batch, s);
+            case 30: if constexpr (EPI != EPI_SILU) return p.N % 96 ? hipErrorInvalidValue : gemm_launch_glds<128, 96, 2, 2, EPI, 3, 64, false, 3, 2>(p, batch, s); else break;
         }
         return hipErrorInvalidValue;
     }
@@ -846,6 +898,14 @@ static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int va
     // runs each): 7.20 ms against 7.37 ms for the register-staged 128 x 128 kernel and 8.0 ms for 3 stages (96 KB: one
     // workgroup per CU — occupancy beats prefetch depth here).  NFAI_GEMM_GLDS=0 selects the register-staged kernel.
     static const int env_glds = getenv("NFAI_GEMM_GLDS") ? atoi(getenv("NFAI_GEMM_GLDS")) : 2;
+    // Round 3: eight waves on a 256 x 128 tile (wave tile 64 x 64 as before), three stages (144 KB, one workgroup per CU): per
+    // CU the same eight waves as two 128 x 128 workgroups, but 48 KB instead of 64 KB of operands per 64-deep K tile through the
+    // CU's load path, which is what bounds these kernels (tools/gemm_bench.py --cold, 512 rows: gate|up of 3B 67.3 -> 58.0 us,
+    // of 1B 43.1 -> 41.5, of 8B 167.7 -> 166.6).  Needs an even number of 128-row blocks.  NFAI_GEMM_W8=0: the 128 x 128 form.
+    static const int env_w8 = getenv("NFAI_GEMM_W8") ? atoi(getenv("NFAI_GEMM_W8")) : 1;
+    if (env_big && env_w8 && env_glds == 2 && p.ksplit == 1 && batch == 1 && p.causal == 0 && p.N % 128 == 0 && ((p.M + 127) / 128) % 2 == 0 &&
+        (uint64_t)((p.M + 255) / 256) * (p.N / 128) >= (uint64_t)n_cu * 3 / 4)
+        return gemm_launch_glds<256, 128, 4, 2, EPI, 3>(p, batch, s);
     if (env_big && p.N % 128 == 0 && big_tiles >= (uint64_t)n_cu * 3 / 2) {
         if (env_glds == 3 && p.ksplit == 1) return gemm_launch_glds<128, 128, 2, 2, EPI, 3>(p, batch, s);
         if (env_glds == 2 && p.ksplit == 1) return gemm_launch_glds<128, 128, 2, 2, EPI, 2>(p, batch, s);
@@ -876,6 +936,19 @@ static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int va
             for (uint32_t bn : {48u, 80u, 96u}) {
                 if (env_bn && (uint32_t)env_bn != bn) continue;
                 if (p.N % bn == 0 && cost(bn) * 100 < best_cost * 97) { best = bn; best_cost = cost(bn); }
+            }
+            // Round 3: a second group of four waves on the same tile; the groups split every K tile's k-steps and add their
+            // accumulators in LDS at the end (these launches have one workgroup per CU: the second wave per SIMD fills the first one's
+            // waits).  BK = 128 where three stages fit the LDS, else four stages of 64 (3B at 512 rows: Wdown 55.3 -> 46.9 us, Wo 23.8
+            // -> 21.4, q|k|v 29.0 -> 27.5; 8B: q|k|v 47.5 -> 37.8, Wo 35.3 -> 29.3, Wdown 116 -> 91; 1B: 17.3 -> 15.9, 18.3 -> 16.0,
+            // 59.7 -> 47.4).  NFAI_GEMM_KS2=0: the four-wave form.
+            static const int env_ks2 = getenv("NFAI_GEMM_KS2") ? atoi(getenv("NFAI_GEMM_KS2")) : 1;
+            const bool bk128 = p.K % 128 == 0;
+            if (env_ks2) {
+                if (best == 48) return bk128 ? gemm_launch_glds<128, 48, 4, 1, EPI, 3, 128, false, 3, 2>(p, batch, s) : gemm_launch_glds<128, 48, 4, 1, EPI, 4, 64, false, 4, 2>(p, batch, s);
+                if (best == 80) return bk128 ? gemm_launch_glds<128, 80, 4, 1, EPI, 3, 128, false, 3, 2>(p, batch, s) : gemm_launch_glds<128, 80, 4, 1, EPI, 4, 64, false, 4, 2>(p, batch, s);
+                if (best == 96) return gemm_launch_glds<128, 96, 4, 1, EPI, 4, 64, false, 4, 2>(p, batch, s);
+                return bk128 ? gemm_launch_glds<128, 64, 4, 1, EPI, 3, 128, false, 3, 2>(p, batch, s) : gemm_launch_glds<128, 64, 4, 1, EPI, 4, 64, false, 4, 2>(p, batch, s);
             }
             if (best == 48) return gemm_launch_glds<128, 48, 4, 1, EPI, 3>(p, batch, s);
             if (best == 80) return gemm_launch_glds<128, 80, 4, 1, EPI, 3>(p, batch, s);
