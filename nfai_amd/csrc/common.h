@@ -151,6 +151,18 @@ hipError_t launch_embed_kq(const void *table, int type, uint64_t n_rows, const u
                            hipStream_t s);
 
 // ---- MFMA prefill (kernels_prefill.hip) ---------------------------------------------------------
+// epi 3 (the q | k | v projection of a prompt chunk): RoPE and every store of RoPEShader / the KV-cache writes in the GEMM's epilogue —
+// row t of the product is position pos0 + t; columns are q heads | k heads | v heads.  cs = cos / sin of the chunk's positions
+// (launch_rope_table).  No fp32 q | k | v round trip through HBM and no separate launch.
+struct GemmRope {
+    const float *cs = nullptr;            // [T][D/2][2]
+    void *qh = nullptr, *kh = nullptr, *vt = nullptr;   // fp16: q [T][H*D], K rows [Hkv][Spad][D], V^T [Hkv][D][Spad]
+    void *kc = nullptr, *vc = nullptr;    // the KV cache of the block (fp32 or fp16)
+    uint64_t pos_stride = 0, head_stride = 0;
+    uint32_t H = 0, Hkv = 0, D = 0, rope_dims = 0, pos0 = 0, Spad = 0, kv_f16 = 0;
+};
+hipError_t launch_rope_table(const float *freqs, uint32_t pos0, uint32_t T, uint32_t D, uint32_t rope_dims, float *cs, hipStream_t s);
+
 struct GemmArgs {  // C[M][N] (+R) = alpha * A[M][K] * B[N][K]^T, fp16 operands, fp32 accumulate / output
     const void *A = nullptr;   // fp16, or fp32 when a_f32 (converted while staging)
     bool a_f32 = false;
@@ -159,6 +171,8 @@ struct GemmArgs {  // C[M][N] (+R) = alpha * A[M][K] * B[N][K]^T, fp16 operands,
     uint32_t n0 = 0, n1 = 0;
     void *C = nullptr;         // fp32 [M][ldc]; fp16 when epi != 0
     int epi = 0;               // 0: fp32 (+R)   1: fp16 out   2: fp16 out = up * silu(gate), B = gate rows, B1 = up rows, N = 2F, C is [M][F]
+                               // 3: RoPE + q / KV-cache stores (rope; C unused)
+    GemmRope rope;
     uint32_t n_cu = 256;
     const float *R = nullptr;  // optional residual, same layout as C (epi 0)
     uint32_t M = 0, N = 0, K = 0, lda = 0, ldb = 0, ldc = 0;

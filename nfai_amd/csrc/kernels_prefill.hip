@@ -44,11 +44,12 @@ struct GemmParams {
                                  // unmasked key of the tile's rows are skipped (they multiply zeros).
     uint32_t causal_pos0;
     NFAI_STAMP_PARAM
+    GemmRope rope;               // EPI_ROPE
     uint32_t ksplit;             // > 1: blockIdx.z owns K tiles [z*KT/ksplit, (z+1)*KT/ksplit) and adds its product atomically
                                  // into C, which the host has initialised with the residual (or zeros)
 };
 
-enum { EPI_F32 = 0, EPI_F16 = 1, EPI_SILU = 2 };
+enum { EPI_F32 = 0, EPI_F16 = 1, EPI_SILU = 2, EPI_ROPE = 3 };
 
 // LDS tile rows are BK halves = CH chunks of 16 B; the chunk index is XORed with the row so that the
 // 16 rows a ds_read_b128 fragment read touches at one k-chunk land in 16 different bank groups
@@ -84,6 +85,95 @@ __device__ __forceinline__ void gemm_store(f32x4 (&acc)[TM][TN], const GemmParam
                     const float g = acc[i][j][r] * p.alpha, u = acc[i][j + 2][r] * p.alpha;
                     if (row < p.M) Ch[(uint64_t)row * p.ldc + col] = (_Float16)(u * silu_ref(g));
                 }
+    } else if constexpr (EPI == EPI_ROPE) {
+        // RoPEShader.cs:249-262 on the accumulators + the stores of k_rope_store_tiles (same arithmetic, same order: the results are
+        // bit-identical to GEMM -> fp32 -> that kernel).  A 16-column block of the tile lies in one head of one of q | k | v (segment
+        // ends and D are multiples of 16), so everything column-dependent is wave-uniform per j; the partner of a rotated pair is
+        // the neighbouring lane (columns 2i, 2i+1 <-> lanes 2i, 2i+1 of the block).
+        const GemmRope &rp = p.rope;
+        const uint32_t half = rp.D / 2, l15 = lane & 15;
+        const uint32_t cwave = n0 + wn * (BN / WN);  // first column of the wave's slice: wave-uniform, like everything derived from it
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        // cos / sin of the lane's rows and column pairs, ALL requested before the first use (a branch or a use between the loads makes
+        // hipcc wait for each one: dependent L2 round trips); pairs that are not rotated read a valid entry and ignore it
+        f32x2 csv[TN][TM][4];
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const uint32_t c0 = cwave + j * 16;
+            const uint32_t cc0 = c0 - (c0 < p.seg_end[0] ? 0u : (c0 < p.seg_end[1] ? p.seg_end[0] : p.seg_end[1]));
+            const uint32_t pr = ((cc0 % rp.D) + l15) >> 1;
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    csv[j][i][r] = *reinterpret_cast<const GLOBAL_AS f32x2 *>((const GLOBAL_AS float *)rp.cs + ((uint64_t)min(rbase + i * 16 + r, p.M - 1) * half + pr) * 2);
+        }
+        _Float16 *const qh = static_cast<_Float16 *>(rp.qh), *const kh = static_cast<_Float16 *>(rp.kh), *const vt = static_cast<_Float16 *>(rp.vt);
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            // scalars of the 16-column block (kept in SGPRs: with a lane-dependent column hipcc selects the cache pointer by a LOAD
+            // from the kernel arguments and then waits vmcnt(0) — i.e. for every earlier store — in front of each store)
+            const uint32_t c0 = __builtin_amdgcn_readfirstlane(cwave + j * 16);
+            const uint32_t seg = c0 < p.seg_end[0] ? 0u : (c0 < p.seg_end[1] ? 1u : 2u);
+            const uint32_t cc0 = c0 - (seg == 0 ? 0u : (seg == 1 ? p.seg_end[0] : p.seg_end[1]));
+            const uint32_t head = cc0 / rp.D, dd = cc0 % rp.D + l15, cc = cc0 + l15;
+            const bool rot = seg < 2 && (dd & ~1u) < rp.rope_dims;
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                const uint32_t row0 = rbase + i * 16;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float a = acc[i][j][r] * p.alpha;
+                    const float other = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, true));
+                    const f32x2 cs = csv[j][i][r];
+                    const float ro = (dd & 1) ? (cs[1] * other + cs[0] * a) : (cs[0] * a - cs[1] * other);
+                    o[r] = rot ? ro : a;
+                }
+                if (seg == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (row0 + r < p.M) qh[(uint64_t)(row0 + r) * rp.H * rp.D + cc] = (_Float16)o[r];
+                    continue;
+                }
+                // K / V rows of the cache (TransformerBlock's KV write) ...
+                const uint64_t at0 = (uint64_t)(rp.pos0 + row0) * rp.pos_stride + (uint64_t)head * rp.head_stride + dd;
+                if (seg == 1) {
+                    if (rp.kv_f16) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if (row0 + r < p.M) static_cast<_Float16 *>(rp.kc)[at0 + r * rp.pos_stride] = (_Float16)o[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if (row0 + r < p.M) static_cast<float *>(rp.kc)[at0 + r * rp.pos_stride] = o[r];
+                    }
+                    // ... and the fp16 K rows the chunk's attention reads
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (row0 + r < p.M) kh[((uint64_t)head * rp.Spad + rp.pos0 + row0 + r) * rp.D + dd] = (_Float16)o[r];
+                } else {
+                    if (rp.kv_f16) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if (row0 + r < p.M) static_cast<_Float16 *>(rp.vc)[at0 + r * rp.pos_stride] = (_Float16)o[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if (row0 + r < p.M) static_cast<float *>(rp.vc)[at0 + r * rp.pos_stride] = o[r];
+                    }
+                    // V^T: the lane's four rows are four consecutive positions of one row of the transposed matrix
+                    _Float16 *dst = vt + ((uint64_t)head * rp.D + dd) * rp.Spad + rp.pos0 + row0;
+                    if (row0 + 3 < p.M && ((rp.pos0 + row0) & 3u) == 0 && (rp.Spad & 3u) == 0) {
+                        *reinterpret_cast<h4 *>(dst) = h4{(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            if (row0 + r < p.M) dst[r] = (_Float16)o[r];
+                    }
+                }
+            }
+        }
     } else if constexpr (EPI == EPI_F16) {
         _Float16 *Ch = static_cast<_Float16 *>(p.C) + (uint64_t)batch * p.c_bs;
 #pragma unroll
@@ -963,6 +1053,45 @@ static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int va
     return gemm_launch<128, 64, 4, 1, 64, EPI>(p, batch, s);
 }
 
+// cos / sin of positions pos0 .. pos0+T-1 for the pairs below rope_dims (the arithmetic of k_rope_store_tiles: theta = freq * pos in
+// fp32, cosf / sinf), once per prompt chunk: every block's q | k | v epilogue reads it.
+__global__ void k_rope_table(const float *freqs, uint32_t pos0, uint32_t half, uint32_t rope_dims, float *cs)
+{
+    const uint32_t t = blockIdx.x, pr = threadIdx.x;
+    if (pr >= half) return;
+    float c = 1.f, sn = 0.f;
+    if (pr * 2 < rope_dims) {
+        const float theta = freqs[pr] * (float)(pos0 + t);
+        c = cosf(theta);
+        sn = sinf(theta);
+    }
+    *reinterpret_cast<f32x2 *>(cs + ((uint64_t)t * half + pr) * 2) = f32x2{c, sn};
+}
+
+hipError_t launch_rope_table(const float *freqs, uint32_t pos0, uint32_t T, uint32_t D, uint32_t rope_dims, float *cs, hipStream_t s)
+{
+    if (T == 0) return hipSuccess;
+    if (D < 2 || D % 2 || D / 2 > 1024) return hipErrorInvalidValue;
+    k_rope_table<<<T, (D / 2 + 63) / 64 * 64, 0, s>>>(freqs, pos0, D / 2, rope_dims, cs);
+    return hipGetLastError();
+}
+
+// the q | k | v projection with the RoPE epilogue: the narrow configurations only (N = (H + 2 Hkv) D is a few thousand columns)
+static hipError_t gemm_pick_rope(GemmParams &p, uint32_t n_cu, hipStream_t s)
+{
+    const uint64_t tm = (p.M + 127) / 128;
+    auto cost = [&](uint32_t bn) { return ((tm * (p.N / bn) + n_cu - 1) / n_cu) * (128 + bn); };
+    uint32_t best = 64;
+    uint64_t best_cost = cost(64);
+    for (uint32_t bn : {48u, 80u, 96u})
+        if (p.N % bn == 0 && cost(bn) * 100 < best_cost * 97) { best = bn; best_cost = cost(bn); }
+    const bool bk128 = p.K % 128 == 0;
+    if (best == 48) return bk128 ? gemm_launch_glds<128, 48, 4, 1, EPI_ROPE, 3, 128, false, 3, 2>(p, 1, s) : gemm_launch_glds<128, 48, 4, 1, EPI_ROPE, 4, 64, false, 4, 2>(p, 1, s);
+    if (best == 80) return bk128 ? gemm_launch_glds<128, 80, 4, 1, EPI_ROPE, 3, 128, false, 3, 2>(p, 1, s) : gemm_launch_glds<128, 80, 4, 1, EPI_ROPE, 4, 64, false, 4, 2>(p, 1, s);
+    if (best == 96) return gemm_launch_glds<128, 96, 4, 1, EPI_ROPE, 4, 64, false, 4, 2>(p, 1, s);
+    return bk128 ? gemm_launch_glds<128, 64, 4, 1, EPI_ROPE, 3, 128, false, 3, 2>(p, 1, s) : gemm_launch_glds<128, 64, 4, 1, EPI_ROPE, 4, 64, false, 4, 2>(p, 1, s);
+}
+
 hipError_t launch_gemm_f16(const GemmArgs &a, hipStream_t s)
 {
     if (a.M == 0 || a.N == 0) return hipSuccess;
@@ -986,6 +1115,15 @@ hipError_t launch_gemm_f16(const GemmArgs &a, hipStream_t s)
     p.causal = a.causal; p.causal_pos0 = a.causal_pos0;
     const uint32_t batch = a.batch ? a.batch : 1;
     const uint32_t n_cu = a.n_cu ? a.n_cu : 256;
+    if (a.epi == EPI_ROPE) {
+        const GemmRope &r = a.rope;
+        if (!a.B1 || !a.B2 || batch != 1 || a.R || a.causal || !r.cs || !r.qh || !r.kh || !r.vt || !r.kc || !r.vc) return hipErrorInvalidValue;
+        if (r.D == 0 || r.D % 16 || r.rope_dims % 2 || r.rope_dims > r.D || r.H == 0 || r.Hkv == 0) return hipErrorInvalidValue;
+        if (a.n0 != r.H * r.D || a.n1 != r.Hkv * r.D || a.N != (r.H + 2 * r.Hkv) * r.D) return hipErrorInvalidValue;
+        if ((p.seg_end[0] | p.seg_end[1] | a.N) % 16) return hipErrorInvalidValue;
+        p.rope = r;
+        return gemm_pick_rope(p, n_cu, s);
+    }
     if (a.epi == EPI_SILU) {
         // N counts gate + up columns; the two segments must be equally long and the output is [M][N/2] fp16
         if (!a.B1 || a.n0 * 2 != a.N || a.R || batch != 1) return hipErrorInvalidValue;

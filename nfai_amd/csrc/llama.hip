@@ -74,6 +74,7 @@ struct Model {
     struct Prefill {
         uint32_t T = 0, Spad = 0;
         uint32_t *toks = nullptr;
+        float *CS = nullptr;       // cos / sin of the chunk's positions [T][D/2][2] (the q | k | v epilogue)
         float *X = nullptr, *H1 = nullptr, *Q = nullptr, *K = nullptr, *V = nullptr, *ATT = nullptr, *G = nullptr, *U = nullptr, *SC = nullptr;
         void *XN = nullptr, *QH = nullptr, *KH = nullptr, *VT = nullptr, *P = nullptr, *ACT = nullptr;  // fp16
         void *WF16 = nullptr;      // one block's matrices widened to fp16 (K-quant models only, allocated on first use)
@@ -734,6 +735,7 @@ NFAI_API int32_t nfai_hip_llama_create(nfai_ctx_t ch, const nfai_llama_desc *des
         DALLOC(w.X, T * d.E * 4);
         DALLOC(w.H1, T * d.E * 4);
         DALLOC(w.Q, T * (HD + 2 * KD) * 4);  // q | k | v columns of one GEMM output
+        DALLOC(w.CS, T * d.D * 4);
         DALLOC(w.ATT, T * HD * 4);
         DALLOC(w.G, T * d.F * 2 * 4);        // gate | up columns of one GEMM output
         DALLOC(w.SC, (size_t)d.H * T * w.Spad * 4);
@@ -780,7 +782,7 @@ NFAI_API int32_t nfai_hip_llama_destroy(nfai_model_t h)
     void *ptrs[] = {m->d_topk, m->d_engparams, m->d_gran, m->d_epoch, m->d_engerr, m->d_pos, m->d_tok, m->d_ring, m->d_freqs, m->d_ropecs, m->d_argmax_part, m->d_attn_part, m->x, m->h,
                     m->q, m->att, m->act, m->logits, m->xn, m->qraw, m->scores, m->wts, m->proj, m->gate, m->up};
     for (void *p : ptrs) if (p) hipFree(p);
-    void *pfp[] = {m->pf.toks, m->pf.X, m->pf.H1, m->pf.Q, m->pf.K, m->pf.V, m->pf.ATT, m->pf.G, m->pf.U, m->pf.SC,
+    void *pfp[] = {m->pf.CS, m->pf.toks, m->pf.X, m->pf.H1, m->pf.Q, m->pf.K, m->pf.V, m->pf.ATT, m->pf.G, m->pf.U, m->pf.SC,
                    m->pf.XN, m->pf.QH, m->pf.KH, m->pf.VT, m->pf.P, m->pf.ACT, m->pf.WF16};
     for (void *p : pfp) if (p) hipFree(p);
     if (m->h_pin) hipHostFree(m->h_pin);
@@ -1137,6 +1139,11 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
         P_TRY(launch_embed_rows_kqt(m->token_embd.ptr, m->token_embd.type, m->token_embd.rows, w.toks, w.X, T, d.E, s));
     else
         P_TRY(launch_embed_rows(m->token_embd.ptr, m->token_embd.type, w.toks, w.X, T, d.E, s));
+    // RoPE and the q / KV-cache stores in the q | k | v GEMM's epilogue (fp16 weights, also widened ones); NFAI_PREFILL_ROPE_FUSED=0:
+    // GEMM -> fp32 q | k | v -> k_rope_store_tiles (bit-identical results, one launch and a 10 MB round trip more per block)
+    const char *env_rf = getenv("NFAI_PREFILL_ROPE_FUSED");
+    const bool rope_fused_ok = !(env_rf && atoi(env_rf) == 0) && d.D % 16 == 0 && d.rope_dims % 2 == 0;
+    if (rope_fused_ok) P_TRY(launch_rope_table(m->d_freqs, pos0, T, d.D, d.rope_dims, w.CS, s));
     for (Layer &Lq : m->layers) {
         Layer L = Lq;
         if (widen) {
@@ -1153,9 +1160,22 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
         }
         P_TRY(launch_rmsnorm_rows(w.X, static_cast<const float *>(L.attn_norm.ptr), w.XN, T, d.E, d.eps, s));
         S_TRY(ahead({&L.wo}));                                                           // while q | k | v computes
-        P_TRY(gemm(w.XN, d.E, L.wq, &L.wk, &L.wv, w.Q, nullptr, QKV, d.E));              // q | k | v in one launch
-        P_TRY(launch_rope_store_rows(w.Q, w.Q + HD, w.Q + HD + KD, w.QH, L.kcache, L.vcache, kvf16, m->kv_pos_stride, m->kv_head_stride,
-                                     m->d_freqs, d.rope_dims, d.H, d.Hkv, d.D, pos0, T, QKV, w.KH, w.VT, Spad, s));
+        if (rope_fused_ok && L.wq.type == NFAI_F16 && L.wk.type == NFAI_F16 && L.wv.type == NFAI_F16) {
+            GemmArgs g;                                                                  // q | k | v + RoPE + q / cache stores in one launch
+            g.A = w.XN; g.lda = d.E; g.ldb = d.E; g.M = T; g.N = QKV; g.K = d.E;
+            g.B = L.wq.ptr; g.B1 = L.wk.ptr; g.B2 = L.wv.ptr; g.n0 = HD; g.n1 = KD;
+            g.epi = 3;
+            g.n_cu = (uint32_t)m->ctx->prop.multiProcessorCount;
+            g.rope.cs = w.CS; g.rope.qh = w.QH; g.rope.kh = w.KH; g.rope.vt = w.VT; g.rope.kc = L.kcache; g.rope.vc = L.vcache;
+            g.rope.pos_stride = m->kv_pos_stride; g.rope.head_stride = m->kv_head_stride;
+            g.rope.H = d.H; g.rope.Hkv = d.Hkv; g.rope.D = d.D; g.rope.rope_dims = d.rope_dims; g.rope.pos0 = pos0; g.rope.Spad = Spad;
+            g.rope.kv_f16 = (uint32_t)kvf16;
+            P_TRY(launch_gemm_f16(g, s));
+        } else {
+            P_TRY(gemm(w.XN, d.E, L.wq, &L.wk, &L.wv, w.Q, nullptr, QKV, d.E));          // q | k | v in one launch
+            P_TRY(launch_rope_store_rows(w.Q, w.Q + HD, w.Q + HD + KD, w.QH, L.kcache, L.vcache, kvf16, m->kv_pos_stride, m->kv_head_stride,
+                                         m->d_freqs, d.rope_dims, d.H, d.Hkv, d.D, pos0, T, QKV, w.KH, w.VT, Spad, s));
+        }
         // earlier positions (chunked prompts) and the zero padding; the chunk's own rows were written above
         P_TRY(launch_kv_to_f16(L.kcache, L.vcache, kvf16, m->kv_pos_stride, m->kv_head_stride, w.KH, w.VT, d.Hkv, d.D, S, Spad, pos0, S, s));
         // attention of the chunk.  Default: one launch (k_attn_prefill: scores, causal softmax and weighted V with the probabilities

@@ -445,6 +445,30 @@ def test_prefill_full_width_block(mgr, dims, chunk):
     m.Dispose()
 
 
+@pytest.mark.parametrize("dims,n,chunk,kv16", [(synth.TINY_D128, 130, 128, False), (synth.TINY_D128, 101, 64, True), (synth.TINY, 37, 64, False)],
+                         ids=["d128-130", "d128-101-kvf16-unaligned-chunks", "tiny-d64"])
+def test_prefill_rope_in_the_gemm_epilogue_is_bit_identical(mgr, dims, n, chunk, kv16, monkeypatch):
+    """RoPE + the q / KV-cache / fp16 K / V^T stores in the q|k|v GEMM's epilogue (the default) against the same GEMM followed by
+    k_rope_store_tiles (NFAI_PREFILL_ROPE_FUSED=0; the switch is read per call): same arithmetic in the same order, so logits and
+    every K / V row must be IDENTICAL, also for a second chunk (pos0 > 0), a ragged last chunk and an fp16 KV cache."""
+    from nfai_amd.llama_model import LlamaModel
+    w = synth.make_weights(dims, seed=72, std=0.05)
+    toks = synth.make_tokens(dims, n, seed=15)
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("NFAI_PREFILL_ROPE_FUSED", fused)
+        m = LlamaModel(mgr, synth.make_metadata(dims), w, 160, max_batch=chunk, kv_f16=kv16)
+        lg = m.Prefill(toks)
+        kv = [m.ReadKV(l, v, pos) for l in range(dims.L) for v in (False, True) for pos in (0, 1, chunk - 1, chunk, n - 1)]
+        nxt, _ = m.Step(int(np.argmax(lg)))  # reads the fp32 / fp16 cache rows the prefill wrote
+        outs.append((lg, kv, nxt))
+        m.Dispose()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(outs[0][2], outs[1][2])
+
+
 # ---- the weight-streaming engine: one launch per block (kernels_engine.hip) ---------------------------------------------
 @pytest.mark.parametrize("mode", ["graph", "eager"])
 def test_engine_decode_matches_oracle(mgr, mode):
