@@ -109,7 +109,7 @@ __device__ __forceinline__ void kqm_kv_store(void *base, int f16, uint64_t idx, 
 // first round's copy can be fetched at kernel start, a microsecond of latency off the tail of the short kernels.
 struct KqmPre { float res; f32x2 cs; uint32_t pos; };
 
-template <int MODE>
+template <int MODE, bool BEGIN = false>
 __device__ __forceinline__ KqmPre kqm_preload(const KqmParams &p, uint32_t u, uint32_t lane)
 {
     KqmPre q;
@@ -122,7 +122,7 @@ __device__ __forceinline__ KqmPre kqm_preload(const KqmParams &p, uint32_t u, ui
         kqm_unit<MODE>(p, u, 0, seg, tile);
         const uint32_t de = ((tile * 16 + r) % p.D) & ~1u;
         q.pos = *((const GLOBAL_AS uint32_t *)p.pos);
-        if (!p.begin.on)  // (first launch of a token: the epilogue takes cos/sin from the workgroup's own table in LDS, begin_bookkeeping)
+        if constexpr (!BEGIN)  // (first launch of a token: the epilogue takes cos/sin from the workgroup's own table in LDS, begin_bookkeeping)
             q.cs = *reinterpret_cast<const GLOBAL_AS f32x2 *>((const GLOBAL_AS float *)p.rope_cs + min(de, p.rope_dims - 2));
     }
     return q;
@@ -165,9 +165,13 @@ __device__ __forceinline__ void kqm_epilogue(const KqmParams &p, uint32_t u, uin
 // in a straight line (the common case for the per-block matrices of a 3B model).  NS = 0: ping-pong over two buffers.
 // (Measured and dropped: an s_barrier between the activation loads and the first weight loads, so that no wave's x
 // queues behind another wave's weights — no effect; four steps in flight — slower, see the step list in DESIGN.md.)
-template <int QT, int MODE, int BPW, bool NORM, int NS>
+// BEGIN (q|k|v with RMSNorm only): the first launch of a token — embedding row, cos/sin table and the token's bookkeeping in this launch.
+// A template parameter and not a kernel argument: as a run-time branch the (dead) bookkeeping code sat between the activation loads and
+// the first weight requests of EVERY q|k|v launch (stamps: weights requested at 1.16 us against 0.4 us in the other launches).
+template <int QT, int MODE, int BPW, bool NORM, int NS, bool BEGIN = false>
 __global__ __launch_bounds__(1024) void k_gemv_kqt(const KqmParams p)
 {
+    static_assert(!BEGIN || (MODE == GEMV_QKV_ROPE && NORM), "a token begins with a normed q|k|v launch");
     // QT = NFAI_KQ_MIXED (QKV only): Q4_K and Q6_K segments in one launch (Q4_K_M files keep attn_v in Q6_K on half of
     // the blocks); the activations are staged in both fragment layouts and every step branches on its segment's type.
     constexpr bool HAS4 = QT != NFAI_Q6_K_T16, HAS6 = QT != NFAI_Q4_K_T16, MIXED = HAS4 && HAS6;
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(1024) void k_gemv_kqt(const KqmParams p)
         const uint32_t bw = wid * BPW + i;
         const uint32_t kk = min(bw, p.NB - 1) * 256 + lane * 4;
         f32x4 v;
-        if (MODE == GEMV_QKV_ROPE && NORM && p.begin.on && p.begin.emb) {  // block-uniform: the token's embedding row (first launch of a token)
+        if (BEGIN && p.begin.emb) {  // block-uniform: the token's embedding row (first launch of a token)
             v = embed_load4(p.begin.emb, p.begin.emb_type, p.begin.emb_rows, p.begin.tok[0], kk, p.K);
             if (blockIdx.x == 0 && bw < p.NB) *reinterpret_cast<f32x4 *>(p.begin.x_out + kk) = v;  // the residual the later launches read
         } else {
@@ -215,11 +219,9 @@ __global__ __launch_bounds__(1024) void k_gemv_kqt(const KqmParams p)
     // keep the activation loads FIRST in program order (vmcnt retires in order: the prologue must not wait behind
     // weights): without this fence hipcc's scheduler interleaves the loads below with them (measured: -2.5 % tokens/s)
     __builtin_amdgcn_sched_barrier(0);
-    const KqmPre pre0 = kqm_preload<MODE>(p, min(blockIdx.x + wid * gridDim.x, p.NU - 1), lane);  // epilogue inputs of round 0
+    const KqmPre pre0 = kqm_preload<MODE, BEGIN>(p, min(blockIdx.x + wid * gridDim.x, p.NU - 1), lane);  // epilogue inputs of round 0
     float *cs_lds = scal + 32 + 48;  // behind the fused ArgMax words
-    if constexpr (MODE == GEMV_QKV_ROPE && NORM) {
-        if (p.begin.on) begin_bookkeeping(p.begin, pre0.pos, cs_lds);
-    }
+    if constexpr (BEGIN) begin_bookkeeping(p.begin, pre0.pos, cs_lds);
     // ---- weights of the first steps
     constexpr int NBUF = NS > 0 ? NS : 2;
     Regs buf[NBUF];
@@ -334,9 +336,9 @@ __global__ __launch_bounds__(1024) void k_gemv_kqt(const KqmParams p)
                 __syncthreads();
                 if (wid <= slot) {  // wave q finishes unit q of this round
                     const uint32_t uq = blockIdx.x + (ui - slot + wid) * gridDim.x;
-                    KqmPre pre = ui == slot ? pre0 : kqm_preload<MODE>(p, uq, lane);
-                    if constexpr (MODE == GEMV_QKV_ROPE && NORM) {
-                        if (p.begin.on) {  // the table this workgroup tabulated before its first step (barrier above)
+                    KqmPre pre = ui == slot ? pre0 : kqm_preload<MODE, BEGIN>(p, uq, lane);
+                    if constexpr (BEGIN) {
+                        {  // the table this workgroup tabulated before its first step (barrier above)
                             uint32_t seg, tile;
                             kqm_unit<MODE>(p, uq, 0, seg, tile);
                             const uint32_t de = ((tile * 16 + (lane & 15)) % p.D) & ~1u;
@@ -634,6 +636,15 @@ static hipError_t q4t_launch(const KqmParams &p, int ns, uint32_t grid, uint32_t
         return hipGetLastError();
     };
     const bool norm = p.gamma != nullptr;
+    if constexpr (MODE == GEMV_QKV_ROPE) {
+        if (p.begin.on) {  // (launch_gemv_kqm: only with gamma)
+            switch (ns) {
+                case 1: return go(k_gemv_kqt<QT, MODE, BPW, true, 1, true>);
+                case 2: return go(k_gemv_kqt<QT, MODE, BPW, true, 2, true>);
+            }
+            return go(k_gemv_kqt<QT, MODE, BPW, true, 0, true>);
+        }
+    }
     switch (ns) {
         case 1: return norm ? go(k_gemv_kqt<QT, MODE, BPW, true, 1>) : go(k_gemv_kqt<QT, MODE, BPW, false, 1>);
         case 2: return norm ? go(k_gemv_kqt<QT, MODE, BPW, true, 2>) : go(k_gemv_kqt<QT, MODE, BPW, false, 2>);

@@ -649,7 +649,7 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void k_gemm_f16_glds(const GemmPar
     static_assert(NW == 4 || NW == 8 || NW == 16, "four, eight or sixteen waves");
     constexpr bool ROLES = NSTB != NST;
     static_assert(!ROLES || NW == 4, "operand roles are written for four waves");
-    static_assert(KS == 1 || (!PIPE && (BK / 32) % KS == 0), "k-steps of a tile are dealt to the wave groups");
+    static_assert(KS == 1 || (BK / 32) % KS == 0, "k-steps of a tile are dealt to the wave groups");
     constexpr int CH = BK / 8, RPI = 64 / CH, TM = BM / WM / 16, TN = BN / WN / 16;  // RPI = tile rows per LDS-DMA instruction
     // LDS-DMA instructions per wave and tile.  Without roles the tile's BM / RPI + BN / RPI instructions are dealt to the four
     // waves round-robin; when BN / RPI is not a multiple of four (BN = 80, 48: tile widths that give exactly 256 workgroups on the
@@ -790,11 +790,13 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void k_gemm_f16_glds(const GemmPar
             for (int j = 0; j < TN; j++) b[j] = *reinterpret_cast<const f16x8 *>(lb + lds_off<CH>(wn * (BN / WN) + j * 16 + (lane & 15), chunk));
         };
         if constexpr (PIPE) {
+            constexpr int KL = KSTEPS / KS;  // this wave group's k-steps of the tile: kg, kg + KS, ...
+            const int k0 = KS > 1 ? (int)kg : 0;
             f16x8 af[2][TM], bf[2][TN];
-            load_frags(0, af[0], bf[0]);
+            load_frags(k0, af[0], bf[0]);
 #pragma unroll
-            for (int ks = 0; ks < KSTEPS; ks++) {
-                if (ks + 1 < KSTEPS) load_frags(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
+            for (int ks = 0; ks < KL; ks++) {
+                if (ks + 1 < KL) load_frags((ks + 1) * KS + k0, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
 #pragma unroll
                 for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -804,8 +806,8 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void k_gemm_f16_glds(const GemmPar
             static_assert(TM * TN >= TM + TN, "more MFMAs than fragment reads per step");
             __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
 #pragma unroll
-            for (int ks = 0; ks < KSTEPS; ks++) {
-                if (ks + 1 < KSTEPS) {
+            for (int ks = 0; ks < KL; ks++) {
+                if (ks + 1 < KL) {
 #pragma unroll
                     for (int q = 0; q < TM + TN; q++) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -911,7 +913,7 @@ static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int va
 {
     if (variant) {  // explicit configuration (tests, tools)
         if (((variant >= 2 && variant <= 4) || variant == 11 || variant == 18 || variant == 19 || (variant >= 21 && variant <= 25)) && p.N % 128 != 0) return hipErrorInvalidValue;
-        if (((variant >= 12 && variant <= 15) || (variant >= 27 && variant <= 34) || variant == 36 || variant == 37 || variant == 40 || variant == 41) && (p.seg_end[0] % 16 || p.seg_end[1] % 16)) return hipErrorInvalidValue;
+        if (((variant >= 12 && variant <= 15) || (variant >= 27 && variant <= 34) || variant == 36 || variant == 37 || variant == 40 || variant == 41 || variant == 45 || variant == 46) && (p.seg_end[0] % 16 || p.seg_end[1] % 16)) return hipErrorInvalidValue;
         switch (variant) {
             case 1: return gemm_launch<128, 64, 4, 1, 64, EPI>(p, batch, s);
             case 2: return gemm_launch<128, 128, 2, 2, 64, EPI>(p, batch, s);
@@ -954,6 +956,10 @@ static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int va
             case 40: if constexpr (EPI != EPI_SILU) return p.N % 80 || p.K % 128 ? hipErrorInvalidValue : gemm_launch_glds<128, 80, 4, 1, EPI, 3, 128, false, 3, 2>(p, batch, s); else break;
             case 41: if constexpr (EPI != EPI_SILU) return p.N % 96 ? hipErrorInvalidValue : gemm_launch_glds<128, 96, 4, 1, EPI, 4, 64, false, 4, 2>(p, batch, s); else break;
             case 42: return gemm_launch_glds<128, 64, 4, 1, EPI, 4, 64, false, 4, 2>(p, batch, s);
+            case 43: return p.N % 128 ? hipErrorInvalidValue : gemm_launch_glds<256, 128, 4, 2, EPI, 3, 64, true>(p, batch, s);
+            case 44: return p.N % 128 ? hipErrorInvalidValue : gemm_launch_glds<256, 128, 4, 2, EPI, 2, 64, true>(p, batch, s);
+            case 45: if constexpr (EPI != EPI_SILU) return p.N % 48 || p.K % 128 ? hipErrorInvalidValue : gemm_launch_glds<128, 48, 4, 1, EPI, 3, 128, true, 3, 2>(p, batch, s); else break;
+            case 46: if constexpr (EPI != EPI_SILU) return p.N % 80 || p.K % 128 ? hipErrorInvalidValue : gemm_launch_glds<128, 80, 4, 1, EPI, 3, 128, true, 3, 2>(p, batch, s); else break;
             case 30: if constexpr (EPI != EPI_SILU) return p.N % 96 ? hipErrorInvalidValue : gemm_launch_glds<128, 96, 2, 2, EPI, 3, 64, false, 3, 2>(p, batch, s); else break;
         }
         return hipErrorInvalidValue;
@@ -995,7 +1001,7 @@ static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int va
     static const int env_w8 = getenv("NFAI_GEMM_W8") ? atoi(getenv("NFAI_GEMM_W8")) : 1;
     if (env_big && env_w8 && env_glds == 2 && p.ksplit == 1 && batch == 1 && p.causal == 0 && p.N % 128 == 0 && ((p.M + 127) / 128) % 2 == 0 &&
         (uint64_t)((p.M + 255) / 256) * (p.N / 128) >= (uint64_t)n_cu * 3 / 4)
-        return gemm_launch_glds<256, 128, 4, 2, EPI, 3>(p, batch, s);
+        return gemm_launch_glds<256, 128, 4, 2, EPI, 3, 64, true>(p, batch, s);  // + pipelined fragment reads: 61.1 -> 57.9 us
     if (env_big && p.N % 128 == 0 && big_tiles >= (uint64_t)n_cu * 3 / 2) {
         if (env_glds == 3 && p.ksplit == 1) return gemm_launch_glds<128, 128, 2, 2, EPI, 3>(p, batch, s);
         if (env_glds == 2 && p.ksplit == 1) return gemm_launch_glds<128, 128, 2, 2, EPI, 2>(p, batch, s);
@@ -1036,7 +1042,7 @@ static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int va
             const bool bk128 = p.K % 128 == 0;
             if (env_ks2) {
                 if (best == 48) return bk128 ? gemm_launch_glds<128, 48, 4, 1, EPI, 3, 128, false, 3, 2>(p, batch, s) : gemm_launch_glds<128, 48, 4, 1, EPI, 4, 64, false, 4, 2>(p, batch, s);
-                if (best == 80) return bk128 ? gemm_launch_glds<128, 80, 4, 1, EPI, 3, 128, false, 3, 2>(p, batch, s) : gemm_launch_glds<128, 80, 4, 1, EPI, 4, 64, false, 4, 2>(p, batch, s);
+                if (best == 80) return bk128 ? gemm_launch_glds<128, 80, 4, 1, EPI, 3, 128, true, 3, 2>(p, batch, s) : gemm_launch_glds<128, 80, 4, 1, EPI, 4, 64, false, 4, 2>(p, batch, s);
                 if (best == 96) return gemm_launch_glds<128, 96, 4, 1, EPI, 4, 64, false, 4, 2>(p, batch, s);
                 return bk128 ? gemm_launch_glds<128, 64, 4, 1, EPI, 3, 128, false, 3, 2>(p, batch, s) : gemm_launch_glds<128, 64, 4, 1, EPI, 4, 64, false, 4, 2>(p, batch, s);
             }
@@ -1087,7 +1093,7 @@ static hipError_t gemm_pick_rope(GemmParams &p, uint32_t n_cu, hipStream_t s)
         if (p.N % bn == 0 && cost(bn) * 100 < best_cost * 97) { best = bn; best_cost = cost(bn); }
     const bool bk128 = p.K % 128 == 0;
     if (best == 48) return bk128 ? gemm_launch_glds<128, 48, 4, 1, EPI_ROPE, 3, 128, false, 3, 2>(p, 1, s) : gemm_launch_glds<128, 48, 4, 1, EPI_ROPE, 4, 64, false, 4, 2>(p, 1, s);
-    if (best == 80) return bk128 ? gemm_launch_glds<128, 80, 4, 1, EPI_ROPE, 3, 128, false, 3, 2>(p, 1, s) : gemm_launch_glds<128, 80, 4, 1, EPI_ROPE, 4, 64, false, 4, 2>(p, 1, s);
+    if (best == 80) return bk128 ? gemm_launch_glds<128, 80, 4, 1, EPI_ROPE, 3, 128, true, 3, 2>(p, 1, s) : gemm_launch_glds<128, 80, 4, 1, EPI_ROPE, 4, 64, false, 4, 2>(p, 1, s);
     if (best == 96) return gemm_launch_glds<128, 96, 4, 1, EPI_ROPE, 4, 64, false, 4, 2>(p, 1, s);
     return bk128 ? gemm_launch_glds<128, 64, 4, 1, EPI_ROPE, 3, 128, false, 3, 2>(p, 1, s) : gemm_launch_glds<128, 64, 4, 1, EPI_ROPE, 4, 64, false, 4, 2>(p, 1, s);
 }
