@@ -252,8 +252,9 @@ def run_single(args):
                    "peak_tflops": 2500.0, "frac_of_mfma_peak": flops / (pf_ms * 1e-3) / 1e12 / 2500.0,
                    "check": {"vs": "the same prompt token by token through the decode path on the GPU", "max_abs_logit_diff": pf_err,
                              "tolerance": pf_tol, "same_argmax": True},
-                   "kernel": "k_gemm_f16_glds (mfma_f32_16x16x32_f16, direct-to-LDS staging; 128x128 / 128x{48,80,96} tiles, SiLU*up and residual "
-                             "epilogues fused) + k_attn_prefill (causal attention of the chunk in one launch)"
+                   "kernel": "k_gemm_f16_glds (mfma_f32_16x16x32_f16, direct-to-LDS staging, eight waves per workgroup: 256x128 tiles on gate|up, "
+                             "128x{48,64,80,96} tiles with two wave groups splitting the k-steps elsewhere; SiLU*up, residual and RoPE + q / KV-cache "
+                             "stores fused into the epilogues) + k_attn_prefill (causal attention of the chunk in one launch)"
                              + ("" if args.quant == "f16" else "; per-block K-quant -> fp16 widening included")}
     else:
         m.SetToken(first_token)

@@ -913,7 +913,7 @@ static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int va
 {
     if (variant) {  // explicit configuration (tests, tools)
         if (((variant >= 2 && variant <= 4) || variant == 11 || variant == 18 || variant == 19 || (variant >= 21 && variant <= 25)) && p.N % 128 != 0) return hipErrorInvalidValue;
-        if (((variant >= 12 && variant <= 15) || (variant >= 27 && variant <= 34) || variant == 36 || variant == 37 || variant == 40 || variant == 41 || variant == 45 || variant == 46) && (p.seg_end[0] % 16 || p.seg_end[1] % 16)) return hipErrorInvalidValue;
+        if (((variant >= 12 && variant <= 15) || (variant >= 27 && variant <= 34) || variant == 36 || variant == 37 || variant == 40 || variant == 41 || variant == 45 || variant == 46 || variant == 47 || variant == 48) && (p.seg_end[0] % 16 || p.seg_end[1] % 16)) return hipErrorInvalidValue;
         switch (variant) {
             case 1: return gemm_launch<128, 64, 4, 1, 64, EPI>(p, batch, s);
             case 2: return gemm_launch<128, 128, 2, 2, 64, EPI>(p, batch, s);
@@ -960,6 +960,8 @@ static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int va
             case 44: return p.N % 128 ? hipErrorInvalidValue : gemm_launch_glds<256, 128, 4, 2, EPI, 2, 64, true>(p, batch, s);
             case 45: if constexpr (EPI != EPI_SILU) return p.N % 48 || p.K % 128 ? hipErrorInvalidValue : gemm_launch_glds<128, 48, 4, 1, EPI, 3, 128, true, 3, 2>(p, batch, s); else break;
             case 46: if constexpr (EPI != EPI_SILU) return p.N % 80 || p.K % 128 ? hipErrorInvalidValue : gemm_launch_glds<128, 80, 4, 1, EPI, 3, 128, true, 3, 2>(p, batch, s); else break;
+            case 47: if constexpr (EPI != EPI_SILU) return p.N % 96 || p.K % 128 ? hipErrorInvalidValue : gemm_launch_glds<64, 96, 2, 2, EPI, 3, 128, false, 3, 2>(p, batch, s); else break;
+            case 48: if constexpr (EPI != EPI_SILU) return p.N % 96 ? hipErrorInvalidValue : gemm_launch_glds<64, 96, 2, 2, EPI, 4, 64, false, 4, 2>(p, batch, s); else break;
             case 30: if constexpr (EPI != EPI_SILU) return p.N % 96 ? hipErrorInvalidValue : gemm_launch_glds<128, 96, 2, 2, EPI, 3, 64, false, 3, 2>(p, batch, s); else break;
         }
         return hipErrorInvalidValue;
