@@ -1509,9 +1509,21 @@ hipError_t launch_softmax_causal_rows(const float *sc, void *p_f16, uint32_t H, 
 // merge their (max, sum, output) through LDS at the end: the dependent chain of a step is walked half as often per wave.
 template <int D, int KG>
 __global__ __launch_bounds__(256 * KG) void k_attn_prefill(const _Float16 *QH, const _Float16 *KH, const _Float16 *VT, _Float16 *O, uint32_t T,
-                                                      uint32_t H, uint32_t G, uint32_t Spad, uint32_t pos0, float scale)
+                                                      uint32_t H, uint32_t G, uint32_t Spad, uint32_t pos0, float scale
+#ifdef NFAI_STAMPS
+                                                      , unsigned long long *stamps
+#endif
+)
 {
-    constexpr int KK = D / 32, DT = D / 16, NST = ATTN_PF_NST;
+#ifdef NFAI_STAMPS
+    // diagnostic build: shader-clock cycles this wave spends waiting for its tile, at the barrier, issuing, in scores + softmax, in P.V
+    unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_s = 0, c_pv = 0, c0 = __builtin_amdgcn_s_memtime(), c1;
+    const unsigned long long c_start = c0;
+#define APF_TICK(acc_) do { __builtin_amdgcn_sched_barrier(0); c1 = __builtin_amdgcn_s_memtime(); acc_ += c1 - c0; c0 = c1; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define APF_TICK(acc_) ((void)0)
+#endif
+    constexpr int KK = D / 32, DT = D / 16, NST = KG > 2 ? 2 : ATTN_PF_NST;  // four key groups: two stages of 4 x 16 KB (D = 128)
     constexpr int KROW = D * 2;                  // bytes of a key row in the K tile (D / 8 chunks of 16 B)
     constexpr int KCH = D / 8;                   // chunks per key row
     constexpr int K_BYTES = 32 * KROW, V_BYTES = D * 64, SUB = K_BYTES + V_BYTES, STAGE = SUB * KG;
@@ -1562,54 +1574,82 @@ __global__ __launch_bounds__(256 * KG) void k_attn_prefill(const _Float16 *QH, c
     f32x4 acc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; dt++) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m = -1.0e38f, l = 0.f;
+    float m = -1.0e30f, l = 0.f;  // (see the softmax below: masked scores are -1e38)
     typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int s2 = 0; s2 < NST - 1; s2++) issue(s2, s2);
     uint32_t cur = 0, fill = NST - 1;
+    APF_TICK(c_issue);
     for (uint32_t st = 0; st < nsteps; st++) {
         wait_vmcnt<(KI / 4 + VI / 4) * (NST - 2)>();
+        APF_TICK(c_wait);
         __builtin_amdgcn_s_barrier();
+        APF_TICK(c_bar);
         issue(st + NST - 1, fill);
+        APF_TICK(c_issue);
         const uint8_t *lk = lds + cur * STAGE + kg * SUB, *lv = lk + K_BYTES;
         const uint32_t k0 = (st * KG + kg) * 32;
-        f32x4 sc[2];
+        // K fragments of both 16-key tiles first — eight 16-byte reads in flight, then the eight MFMAs, the two tiles' chains
+        // alternating (left to itself hipcc read one fragment, waited lgkmcnt(0), multiplied, eight times in a row: the scores +
+        // softmax part of a step took 1570 cycles per wave, tools/attn_pf_stamps.py)
+        f16x8 kf[2][KK];
 #pragma unroll
         for (int kt = 0; kt < 2; kt++) {
-            sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
             const uint32_t key = kt * 16 + qi;
 #pragma unroll
-            for (int kk = 0; kk < KK; kk++) {
-                const f16x8 kf = *reinterpret_cast<const f16x8 *>(lk + key * KROW + (((kk * 4 + g) ^ (key & (KCH - 1) & 15)) * 16));
-                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kk], sc[kt], 0, 0, 0);
-            }
+            for (int kk = 0; kk < KK; kk++)
+                kf[kt][kk] = *reinterpret_cast<const f16x8 *>(lk + key * KROW + (((kk * 4 + g) ^ (key & (KCH - 1) & 15)) * 16));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 sc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++)
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt][kk], qf[kk], sc[kt], 0, 0, 0);
+        // scale; the causal limit only where the sub-tile reaches past the first of the wave's 16 rows (wave-uniform)
+        if (k0 + 31 <= pos0 + q0) {
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++) sc[kt] *= scale;
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t key = k0 + kt * 16 + g * 4 + r;
+                    sc[kt][r] = key <= my_last ? sc[kt][r] * scale : -1.0e38f;
+                }
         }
         float mx = m;
 #pragma unroll
         for (int kt = 0; kt < 2; kt++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const uint32_t key = k0 + kt * 16 + g * 4 + r;
-                sc[kt][r] = key <= my_last ? sc[kt][r] * scale : -1.0e38f;
-                mx = fmaxf(mx, sc[kt][r]);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+            for (int r = 0; r < 4; r++) mx = fmaxf(mx, sc[kt][r]);
+        {   // max over the four lane groups of a query (lanes q, q + 16, q + 32, q + 48) inside the vector ALU: v_permlane16_swap /
+            // v_permlane32_swap hand every row its neighbours' values (gfx950); the shuffle form is two dependent trips through the LDS crossbar
+            uint32_t b = __builtin_bit_cast(uint32_t, mx);
+            auto r16 = __builtin_amdgcn_permlane16_swap(b, b, false, false);  // [0]: rows {0,0,2,2}, [1]: rows {1,1,3,3}
+            mx = fmaxf(__builtin_bit_cast(float, (uint32_t)r16[0]), __builtin_bit_cast(float, (uint32_t)r16[1]));
+            b = __builtin_bit_cast(uint32_t, mx);
+            auto r32 = __builtin_amdgcn_permlane32_swap(b, b, false, false);  // [0]: rows {0,1,0,1}, [1]: rows {2,3,2,3}
+            mx = fmaxf(__builtin_bit_cast(float, (uint32_t)r32[0]), __builtin_bit_cast(float, (uint32_t)r32[1]));
+        }
         const float corr = __expf(fmaxf(m - mx, -80.f));  // 1 when nothing changes; e^-80 ~ 0 while nothing has been seen (acc and l are 0 then)
         f16x8 pf;
         float ls = 0.f;
+        // A masked key carries -1e38 and the running maximum never falls below -1e30 (its initial value): its exponent clamps to -80
+        // and e^-80 rounds to an fp16 ZERO — exactly what the reference's masked-out weight is — without a branch per key.
 #pragma unroll
         for (int kt = 0; kt < 2; kt++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const uint32_t key = k0 + kt * 16 + g * 4 + r;
-                const float e = key <= my_last ? __expf(fminf(fmaxf(sc[kt][r] - mx, -80.f), 80.f)) : 0.f;  // AttentionSoftmaxShader.cs:160-166
+                const float e = __expf(fminf(fmaxf(sc[kt][r] - mx, -80.f), 80.f));  // AttentionSoftmaxShader.cs:160-166
                 const _Float16 eh = (_Float16)e;
                 pf[kt * 4 + r] = eh;
                 ls += (float)eh;  // the sum of what is actually multiplied
             }
         l = l * corr + ls;
         m = mx;
+        APF_TICK(c_s);
 #pragma unroll
         for (int dt = 0; dt < DT; dt++) {
             acc[dt] *= corr;
@@ -1623,30 +1663,51 @@ __global__ __launch_bounds__(256 * KG) void k_attn_prefill(const _Float16 *QH, c
         }
         cur = cur + 1 == NST ? 0 : cur + 1;
         fill = fill + 1 == NST ? 0 : fill + 1;
+        APF_TICK(c_pv);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus DMAs of the last iterations must not outlive the workgroup's LDS
-    if constexpr (KG == 2) {
-        // merge the two key groups of a query tile through LDS (the ring is free now): group 1 hands (max, partial sum, output) over
+#ifdef NFAI_STAMPS
+    {
+        APF_TICK(c_wait);
+        const uint32_t wg = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wave_all;
+        if (stamps && wg < STAMP_WAVES && lane == 0) {
+            unsigned long long *o = stamps + (size_t)wg * STAMP_WORDS;
+            o[0] = c_start; o[1] = c_wait; o[2] = c_bar; o[3] = c_issue; o[4] = c_s; o[5] = c_pv; o[6] = c1; o[7] = ((unsigned long long)nsteps << 32) | qb;
+        }
+    }
+#endif
+#undef APF_TICK
+    if constexpr (KG >= 2) {
+        // merge the key groups of a query tile through LDS (the ring is free now): groups 1.. hand (max, partial sum, output) over,
+        // group 0 folds them in, in group order
+        constexpr uint32_t MB = 2 + DT * 4;
+        static_assert((KG - 1) * 256 * MB * 4 <= NST * STAGE, "merge records fit the ring");
         __syncthreads();
-        float *mb = reinterpret_cast<float *>(lds) + (size_t)(wave * 64 + lane) * (2 + DT * 4);
-        if (kg == 1) {
-            mb[0] = m;
-            mb[1] = l;
+        float *mb = reinterpret_cast<float *>(lds) + (size_t)(wave * 64 + lane) * MB;
+        if (kg != 0) {
+            float *w = mb + (size_t)(kg - 1) * 256 * MB;
+            w[0] = m;
+            w[1] = l;
 #pragma unroll
             for (int dt = 0; dt < DT; dt++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) mb[2 + dt * 4 + r] = acc[dt][r];
+                for (int r = 0; r < 4; r++) w[2 + dt * 4 + r] = acc[dt][r];
         }
         __syncthreads();
-        if (kg == 1) return;
-        const float m1 = mb[0], l1 = mb[1];
-        const float M = fmaxf(m, m1);
-        const float a0 = __expf(fmaxf(m - M, -80.f)), a1 = __expf(fmaxf(m1 - M, -80.f));
-        l = l * a0 + l1 * a1;
+        if (kg != 0) return;
 #pragma unroll
-        for (int dt = 0; dt < DT; dt++)
+        for (int g2 = 1; g2 < KG; g2++) {
+            const float *rd = mb + (size_t)(g2 - 1) * 256 * MB;
+            const float m1 = rd[0], l1 = rd[1];
+            const float M = fmaxf(m, m1);
+            const float a0 = __expf(fmaxf(m - M, -80.f)), a1 = __expf(fmaxf(m1 - M, -80.f));
+            l = l * a0 + l1 * a1;
+            m = M;
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc[dt][r] = acc[dt][r] * a0 + mb[2 + dt * 4 + r] * a1;
+            for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[dt][r] = acc[dt][r] * a0 + rd[2 + dt * 4 + r] * a1;
+        }
     }
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
@@ -1671,11 +1732,16 @@ hipError_t launch_attn_prefill(const void *qh, const void *kh, const void *vt, v
     const float scale = 1.0f / sqrtf((float)D);  // AttentionScoreCalculationShader.cs:93
     // two key groups per query tile (512 threads) unless NFAI_PREFILL_ATTN_KG=1
     static const int env_kg = getenv("NFAI_PREFILL_ATTN_KG") ? atoi(getenv("NFAI_PREFILL_ATTN_KG")) : 2;
-    const int kg = (env_kg == 1 || Spad % 64) ? 1 : 2;  // a step of two key groups covers 64 keys
-    const size_t lds = (size_t)ATTN_PF_NST * (32 * D * 2 + D * 64) * kg;
+    const int kg = (env_kg == 1 || Spad % 64) ? 1 : ((env_kg == 4 && Spad % 128 == 0) ? 4 : 2);  // a step of KG key groups covers 32 KG keys
+    const size_t lds = (size_t)(kg > 2 ? 2 : ATTN_PF_NST) * (32 * D * 2 + D * 64) * kg;
     const _Float16 *q = static_cast<const _Float16 *>(qh), *k = static_cast<const _Float16 *>(kh), *v = static_cast<const _Float16 *>(vt);
     _Float16 *o = static_cast<_Float16 *>(out_f16);
     const uint32_t G = H / Hkv;
+#ifdef NFAI_STAMPS
+#define NFAI_APF_LAUNCH(D_, KG_) k_attn_prefill<D_, KG_><<<grid, 256 * KG_, lds, s>>>(q, k, v, o, T, H, G, Spad, pos0, scale, stamp_next_slot("attn_prefill", grid.x * grid.y, 256 * KG_))
+#else
+#define NFAI_APF_LAUNCH(D_, KG_) k_attn_prefill<D_, KG_><<<grid, 256 * KG_, lds, s>>>(q, k, v, o, T, H, G, Spad, pos0, scale)
+#endif
 #define NFAI_APF(D_, KG_)                                                                                                                  \
     do {                                                                                                                                   \
         static bool attr_set = false;                                                                                                      \
@@ -1684,11 +1750,12 @@ hipError_t launch_attn_prefill(const void *qh, const void *kh, const void *vt, v
             if (e != hipSuccess) return e;                                                                                                 \
             attr_set = true;                                                                                                               \
         }                                                                                                                                  \
-        k_attn_prefill<D_, KG_><<<grid, 256 * KG_, lds, s>>>(q, k, v, o, T, H, G, Spad, pos0, scale);                                       \
+        NFAI_APF_LAUNCH(D_, KG_);                                                                                                          \
     } while (0)
-    if (D == 128) { if (kg == 2) NFAI_APF(128, 2); else NFAI_APF(128, 1); }
-    else { if (kg == 2) NFAI_APF(64, 2); else NFAI_APF(64, 1); }
+    if (D == 128) { if (kg == 4) NFAI_APF(128, 4); else if (kg == 2) NFAI_APF(128, 2); else NFAI_APF(128, 1); }
+    else { if (kg == 4) NFAI_APF(64, 4); else if (kg == 2) NFAI_APF(64, 2); else NFAI_APF(64, 1); }
 #undef NFAI_APF
+#undef NFAI_APF_LAUNCH
     return hipGetLastError();
 }
 
