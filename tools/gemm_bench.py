@@ -22,7 +22,9 @@ def main():
     T = int(args[0]) if args else 512
     mgr = HipBufferManager(0)
     shapes = {"3b": ((5120, 3072), (3072, 3072), (16384, 3072), (3072, 8192)), "8b": ((6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336)),
-              "1b": ((3072, 2048), (2048, 2048), (16384, 2048), (2048, 8192))}[os.environ.get("GEMM_MODEL", "3b")]
+              "1b": ((3072, 2048), (2048, 2048), (16384, 2048), (2048, 8192)),
+              # split-K proxies of 3B's Wdown / Wo: the same number of 128 x 96 tiles as two K halves would have, half the K each
+              "splitk-proxy": ((6144, 4096), (6144, 1536))}[os.environ.get("GEMM_MODEL", "3b")]
     for (N, K) in shapes:
         nw = max(2, -(-640 * 2**20 // (N * K * 2))) if cold else 1
         pa = ShaderProperty(mgr, T * K, np.float16)
