@@ -862,9 +862,10 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void k_gemm_f16_glds(const GemmPar
     gemm_store<BM, BN, WM, WN, EPI, TM, TN>(acc, p, m0, n0, wm, wn, lane, batch);
 #ifdef NFAI_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    GEMM_TICK(c_issue);  // epilogue counted with the issue bucket's neighbour below
-    _st.t[0] = c_start; _st.t[1] = c_wait; _st.t[2] = c_bar; _st.t[3] = c_issue; _st.t[4] = c_mul; _st.t[5] = c1; _st.t[6] = KT;
-    STAMP_FLUSH(p.stamps, blockIdx.x * NW + wave, 7);
+    unsigned long long c_epi = 0;
+    GEMM_TICK(c_epi);  // epilogue: group sums (KS > 1), residual loads, stores, until the stores are acknowledged
+    _st.t[0] = c_start; _st.t[1] = c_wait; _st.t[2] = c_bar; _st.t[3] = c_issue; _st.t[4] = c_mul; _st.t[5] = c1; _st.t[6] = KT; _st.t[7] = c_epi;
+    STAMP_FLUSH(p.stamps, blockIdx.x * NW + wave, 8);
 #endif
 #undef GEMM_TICK
 }

@@ -56,7 +56,7 @@ def main():
         med = lambda a: float(np.median(a))  # noqa: E731
         out["shapes"][f"{name} M={T} N={N} K={K}"] = {
             "waves": int(t.shape[0]), "k_tiles": kt, "total": med(total), "wait_for_tile_vmcnt": med(t[:, 1]), "barrier": med(t[:, 2]),
-            "issue_dma_and_epilogue": med(t[:, 3]), "fragment_reads_and_mfma": med(t[:, 4]),
+            "issue_dma": med(t[:, 3]), "fragment_reads_and_mfma": med(t[:, 4]), "epilogue_until_stores_acknowledged": med(t[:, 7]),
             "per_k_tile": {"wait": round(med(t[:, 1]) / kt, 1), "barrier": round(med(t[:, 2]) / kt, 1), "issue": round(med(t[:, 3]) / kt, 1),
                            "reads_and_mfma": round(med(t[:, 4]) / kt, 1), "total": round(med(total) / kt, 1)}}
         buf.zero_()
