@@ -312,6 +312,9 @@ def run_bench_pipeline(args):
     rehearsal = os.environ.get("NFAI_PP_REHEARSAL") == "1"
     if rehearsal:
         local = 0
+        # the ranks share one card: its CUs are divided between their launches, so the slices' workgroups of an attention launch are not
+        # all resident at once and the granule hand-off (which waits for them) would give up — the ticket form never waits
+        os.environ.setdefault("NFAI_ATTN_POLL", "0")
     torch.cuda.set_device(local)
     # Exchange step: the C ABI's own RCCL communicator (nfai_hip_pp_*, what a C# host calls) unless NFAI_PP_COMM=torch
     # (torch.distributed's NCCL binding) or the one-card rehearsal (gloo through host copies).  Host-side control traffic
