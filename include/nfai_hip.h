@@ -265,7 +265,10 @@ int32_t nfai_hip_llama_decode_enqueue(nfai_model_t model, uint32_t n_steps);
 int32_t nfai_hip_llama_set_token(nfai_model_t model, uint32_t token);
 int32_t nfai_hip_llama_fetch_tokens(nfai_model_t model, uint32_t n, uint32_t *tokens_out);
 /* Batched prompt ingestion on the MFMA path (the reference feeds the prompt token by token,
- * LlamaModel.cs:103-126): n tokens at positions pos..pos+n-1; logits of the LAST token. */
+ * LlamaModel.cs:103-126): n tokens at positions pos..pos+n-1; logits of the LAST token.
+ * K-quant models: the first call widens every block's matrices to fp16 copies for the MFMA GEMMs (2 bytes per weight, kept
+ * until a tensor is replaced) when all of them fit a quarter of the device's memory, else one block's scratch is re-widened
+ * per block (NFAI_PREFILL_WIDE_ALL=0 / 1 forces either); the decode path always streams the quantised blocks. */
 int32_t nfai_hip_llama_prefill(nfai_model_t model, const uint32_t *tokens, uint32_t n, float *logits_last_host);
 /* Pipeline stage: run this stage's blocks on a hidden state resident in device memory.
  * First stage: hidden_in == NULL and `token` is embedded.  Last stage: lm_head + argmax run and

@@ -77,8 +77,11 @@ struct Model {
         float *CS = nullptr;       // cos / sin of the chunk's positions [T][D/2][2] (the q | k | v epilogue)
         float *X = nullptr, *H1 = nullptr, *Q = nullptr, *K = nullptr, *V = nullptr, *ATT = nullptr, *G = nullptr, *U = nullptr, *SC = nullptr;
         void *XN = nullptr, *QH = nullptr, *KH = nullptr, *VT = nullptr, *P = nullptr, *ACT = nullptr;  // fp16
-        void *WF16 = nullptr;      // one block's matrices widened to fp16 (K-quant models only, allocated on first use)
-        uint64_t wf16_bytes = 0;
+        void *WF16 = nullptr;      // K-quant models: the blocks' matrices widened to fp16 for the MFMA GEMMs (allocated on first use) —
+        uint64_t wf16_bytes = 0;   // one slot per block, each widened ONCE and kept, when that fits the memory budget (288 GB of HBM: 6.4 GB
+        bool wf16_all = false;     // at 3B, 16 GB at 8B); otherwise one slot, re-widened for every block of every chunk
+        uint64_t wf16_slot = 0;    // bytes per block slot
+        std::vector<uint8_t> wf16_done;  // per block: slot holds the current weights
     } pf;
     uint32_t pos_host = 0;
     const float *x_last = nullptr;   // where the last enqueued token left the hidden state (m->x, or m->h on the engine path)
@@ -844,6 +847,7 @@ static int set_tensor_impl(Model *m, const char *name, int type, uint64_t rows, 
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return fail_free(nt.ptr, nullptr, fail(NFAI_ERR_HIP, "set_tensor(%s): upload failed: %s", name, hipGetErrorString(e)));
     }
+    std::fill(m->pf.wf16_done.begin(), m->pf.wf16_done.end(), 0);  // the kept fp16 copies of the K-quant prefill are of the old weights
     m->finalized = false;  // graphs captured over the old pointer are dropped by the next finalize
     if (t->owned && t->ptr) {
         hipStreamSynchronize(s);  // nothing enqueued may still read the old storage
@@ -879,6 +883,7 @@ NFAI_API int32_t nfai_hip_llama_share_tensors(nfai_model_t h, nfai_model_t donor
         share(L.attn_norm, S.attn_norm); share(L.wq, S.wq); share(L.wk, S.wk); share(L.wv, S.wv); share(L.wo, S.wo);
         share(L.ffn_norm, S.ffn_norm); share(L.wgate, S.wgate); share(L.wup, S.wup); share(L.wdown, S.wdown);
     }
+    std::fill(m->pf.wf16_done.begin(), m->pf.wf16_done.end(), 0);
     m->finalized = false;
     return NFAI_OK;
 }
@@ -1146,17 +1151,21 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
     if (rope_fused_ok) P_TRY(launch_rope_table(m->d_freqs, pos0, T, d.D, d.rope_dims, w.CS, s));
     for (Layer &Lq : m->layers) {
         Layer L = Lq;
-        if (widen) {
-            uint64_t off = 0;
+        if (widen && w.WF16) {
+            const size_t li = (size_t)(&Lq - m->layers.data());
+            const bool kept = w.wf16_all && w.wf16_done[li];  // widened by an earlier chunk / prefill and still current
+            uint64_t off = w.wf16_all ? li * w.wf16_slot : 0;
+            const uint64_t end = off + w.wf16_slot;
             for (Tensor *tq : {&L.wq, &L.wk, &L.wv, &L.wo, &L.wgate, &L.wup, &L.wdown}) {
                 if (tq->type == NFAI_F16) continue;
                 const uint64_t bytes = tq->rows * tq->cols * 2;
-                if (off + bytes > w.wf16_bytes) return fail(NFAI_ERR_STATE, "prefill: fp16 weight scratch too small");
+                if (off + bytes > end) return fail(NFAI_ERR_STATE, "prefill: fp16 weight scratch too small");
                 void *dst = static_cast<uint8_t *>(w.WF16) + off;
-                P_TRY(launch_dequant_t16_f16(tq->ptr, tq->type, tq->rows, tq->cols, dst, s));
+                if (!kept) P_TRY(launch_dequant_t16_f16(tq->ptr, tq->type, tq->rows, tq->cols, dst, s));
                 tq->ptr = dst; tq->type = NFAI_F16; tq->owned = false;
                 off += (bytes + 255) / 256 * 256;
             }
+            if (w.wf16_all) w.wf16_done[li] = 1;
         }
         P_TRY(launch_rmsnorm_rows(w.X, static_cast<const float *>(L.attn_norm.ptr), w.XN, T, d.E, d.eps, s));
         S_TRY(ahead({&L.wo}));                                                           // while q | k | v computes
@@ -1287,8 +1296,20 @@ NFAI_API int32_t nfai_hip_llama_prefill(nfai_model_t h, const uint32_t *tokens, 
             need = std::max(need, b);
         }
         if (need) {
-            DALLOC(m->pf.WF16, need);
-            m->pf.wf16_bytes = need;
+            // Keep every block's fp16 copy (widened once, at the first prefill) when all of them fit a quarter of the device's memory
+            // and leave 4 GB free: the per-block widening is a quarter of a K-quant prefill (64 us of 230 per block at 3B).  The decode
+            // path never reads these copies.  NFAI_PREFILL_WIDE_ALL=0 / 1 forces one slot / all slots.
+            const uint64_t all = need * m->layers.size();
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            const char *env = getenv("NFAI_PREFILL_WIDE_ALL");
+            const bool fits = all + (4ull << 30) <= free_b;
+            const bool want = env ? atoi(env) != 0 : all <= total_b / 4;
+            m->pf.wf16_all = want && fits;
+            m->pf.wf16_slot = need;
+            m->pf.wf16_bytes = m->pf.wf16_all ? all : need;
+            DALLOC(m->pf.WF16, m->pf.wf16_bytes);
+            m->pf.wf16_done.assign(m->layers.size(), 0);
         }
     }
     for (uint32_t done = 0; done < n;) {

@@ -206,6 +206,46 @@ def test_prefill_mfma_kquant(mgr, n, chunk):
     m.Dispose()
 
 
+def test_prefill_kept_fp16_copies_match_the_per_block_scratch(mgr, monkeypatch):
+    """K-quant prefill: the blocks' matrices are widened to fp16 once and kept (the default while they fit a quarter of the HBM) or
+    re-widened into one block's scratch for every block and chunk (NFAI_PREFILL_WIDE_ALL=0, read when the scratch is allocated).
+    Same kernels on the same bytes: logits and K / V rows must be IDENTICAL — for the first prefill (which widens), for a second one
+    that reuses the kept copies, and after a weight was replaced (the copies are re-made)."""
+    from nfai_amd._lib import call
+    from nfai_amd.llama_model import LlamaModel, QuantTensor
+    dims = synth.TINY_D128
+    w = synth.make_weights(dims, seed=68, std=0.05)
+    wq = {}
+    for name, a in w.items():
+        if a.ndim == 1:
+            wq[name] = a
+            continue
+        qt = Q6_K if name.endswith(("attn_v.weight", "ffn_down.weight")) or name.startswith(("token_embd", "output.")) else Q4_K
+        wq[name] = QuantTensor(quantize(a.astype(np.float32), qt)[0], qt, a.shape)
+    dd = dict(E=dims.E, L=dims.L, H=dims.H, Hkv=dims.Hkv, D=dims.D, F=dims.F, V=dims.V, eps=1e-5, rope_dims=dims.D, rope_base=500000.0)
+    toks = synth.make_tokens(dims, 100, seed=22)
+    other = "blk.1.ffn_gate.weight"
+    repl = QuantTensor(quantize((0.5 * w[other]).astype(np.float32), Q4_K)[0], Q4_K, w[other].shape)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NFAI_PREFILL_WIDE_ALL", mode)
+        m = LlamaModel(mgr, synth.make_metadata(dims), wq, 128, dims=dd, max_batch=64)
+        a = m.Prefill(toks)
+        kv_a = m.ReadKV(dims.L - 1, True, 99)
+        m.Reset()
+        b = m.Prefill(toks)            # mode 1: every block's copy is reused
+        assert np.array_equal(a, b) and np.array_equal(kv_a, m.ReadKV(dims.L - 1, True, 99))
+        m.SetTensor(other, repl)       # a replaced weight must reach the prefill GEMMs
+        call("nfai_hip_llama_finalize", m.handle)
+        m.Reset()
+        c = m.Prefill(toks)
+        assert not np.array_equal(a, c)
+        outs[mode] = (a, kv_a, c)
+        m.Dispose()
+    for x, y in zip(outs["1"], outs["0"]):
+        assert np.array_equal(x, y)
+
+
 def test_prefill_fused_dequant_in_child_process():
     """The dequant-in-LDS prefill (k_gemm_kq, NFAI_PREFILL_FUSED=1) at model level.  The switch is read once per process, so the
     same Q4_K_M-style prefill test runs again in a child process with the variable set; the child's interpreter loads the
