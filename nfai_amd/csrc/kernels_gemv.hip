@@ -201,9 +201,21 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
     const uint32_t nwaves = blockDim.x >> 6;
     const uint32_t wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t gw = blockIdx.x * nwaves + wid, tw = gridDim.x * nwaves;
+#ifndef GEMV_INTERLEAVE
+#define GEMV_INTERLEAVE 1
+#endif
+#if GEMV_INTERLEAVE
+    // groups dealt round-robin over all waves of the launch: every wave (and with it every XCD) reads rows from all over the matrix
+    const uint32_t total_groups = (p.NU + UPW - 1) / UPW;
+    const uint32_t ngroups = total_groups > gw ? (total_groups - gw + tw - 1) / tw : 0;
+    const uint32_t u_end = p.NU;
+    auto unit_at = [&](uint32_t g, uint32_t q) { return (g * tw + gw) * UPW + q; };
+#else
     const uint32_t u_begin = (uint32_t)(((uint64_t)p.NU * gw) / tw);
     const uint32_t u_end = (uint32_t)(((uint64_t)p.NU * (gw + 1)) / tw);
     const uint32_t ngroups = (u_end - u_begin + UPW - 1) / UPW;
+    auto unit_at = [&](uint32_t g, uint32_t q) { return u_begin + g * UPW + q; };
+#endif
     const uint32_t cpg = p.KC / U;  // K-chunk groups per unit group
     const uint32_t nsteps = ngroups * cpg;
     const uint32_t kpad = p.KC * 64 * EPL;
@@ -219,7 +231,7 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
             const uint32_t g = st / cpg, cg = st % cpg;
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const uint32_t u = min(min(u_begin + g * UPW + r / RPU, u_end - 1), p.NU - 1);
+                const uint32_t u = min(min(unit_at(g, r / RPU), u_end - 1), p.NU - 1);
                 const uint8_t *row = row_ptr<MODE>(p, u, r % RPU);
 #pragma unroll
                 for (int j = 0; j < U; j++) {
@@ -258,7 +270,7 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
     // cos,sin pair) and the position are requested now, with the activations
     float e0 = 0.f, e1 = 0.f;
     float *cs_lds = BEGIN ? xs + kpad + 16 + 48 : nullptr;  // first launch of a token: cos / sin of the position tabulated in LDS
-    if constexpr (!BEGIN) epilogue_prefetch<MODE>(p, min(min(u_begin + min(lane, (uint32_t)UPW - 1), u_end - 1), p.NU - 1), e0, e1);
+    if constexpr (!BEGIN) epilogue_prefetch<MODE>(p, min(min(unit_at(0, min(lane, (uint32_t)UPW - 1)), u_end - 1), p.NU - 1), e0, e1);
     const uint32_t pos_v = (MODE == GEMV_QKV_ROPE) ? p.pos[0] : 0u;
     if constexpr (BEGIN) begin_bookkeeping(p.begin, pos_v, cs_lds);
 
@@ -270,7 +282,7 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
         if (iw.cg == 0) {
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const uint32_t u = min(min(u_begin + iw.g * UPW + r / RPU, u_end - 1), p.NU - 1);
+                const uint32_t u = min(min(unit_at(iw.g, r / RPU), u_end - 1), p.NU - 1);
                 rows[r] = row_ptr<MODE>(p, u, r % RPU);
             }
         }
@@ -335,7 +347,7 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
 #ifndef GEMV_B_EARLY
     issue(bufB);
 #endif
-    if constexpr (BEGIN) epilogue_prefetch<MODE>(p, min(min(u_begin + min(lane, (uint32_t)UPW - 1), u_end - 1), p.NU - 1), e0, e1, cs_lds);  // (table: barrier above)
+    if constexpr (BEGIN) epilogue_prefetch<MODE>(p, min(min(unit_at(0, min(lane, (uint32_t)UPW - 1)), u_end - 1), p.NU - 1), e0, e1, cs_lds);  // (table: barrier above)
     STAMP(2);  // x (normalised) is in LDS, second weight step issued
 
     float acc[R];
@@ -356,7 +368,7 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
             for (int r = 0; r < R; r++) acc[r] = wave_sum(acc[r]);
 #pragma unroll
             for (int q = 0; q < UPW; q++) {
-                const uint32_t u = u_begin + cw.g * UPW + q;
+                const uint32_t u = unit_at(cw.g, q);
                 // lane q finishes unit q (uniform values; spreads the stores over lanes)
                 if (lane == (uint32_t)q && u < u_end) {
                     epilogue<MODE>(p, u, acc[q * RPU], RPU == 2 ? acc[q * RPU + RPU - 1] : 0.f, e0, e1, pos_v);
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
 #pragma unroll
             for (int r = 0; r < R; r++) acc[r] = 0.f;
             // what the NEXT group's epilogue reads, a whole group ahead
-            epilogue_prefetch<MODE>(p, min(min(u_begin + (cw.g + 1) * UPW + min(lane, (uint32_t)UPW - 1), u_end - 1), p.NU - 1), e0, e1, cs_lds);
+            epilogue_prefetch<MODE>(p, min(min(unit_at(cw.g + 1, min(lane, (uint32_t)UPW - 1)), u_end - 1), p.NU - 1), e0, e1, cs_lds);
         }
         cw.next(cpg);
     };

@@ -157,6 +157,20 @@ def main():
                 d.setdefault("all_granules_seen_after_own_publish", []).extend(mg[:, 5] - mg[:, 4])
                 d.setdefault("merge_and_store", []).extend(mg[:, 7] - mg[:, 5])
         else:
+            # who finishes late?  waves are flushed in order (workgroup * waves per workgroup + wave): by XCD (workgroup id mod 8: the
+            # dispatcher deals workgroups round-robin over the eight XCDs) and by workgroup
+            wpb_ = max(1, L["block"] // 64)
+            if L["t"].shape[0] == L["grid"] * wpb_:
+                rel_end = (end - L["t0"]).reshape(L["grid"], wpb_)
+                wg_end = rel_end.max(axis=1)
+                xcd_mean = np.array([wg_end[x::8].mean() for x in range(8)])
+                d.setdefault("xcd_mean_end", []).append(xcd_mean)
+                d.setdefault("xcd_spread_of_means", []).append(float(xcd_mean.max() - xcd_mean.min()))
+                d.setdefault("wg_end_p50", []).append(float(np.median(wg_end)))
+                d.setdefault("wg_end_p90", []).append(float(np.percentile(wg_end, 90)))
+                d.setdefault("within_wg_wave_spread", []).append(float(np.median(rel_end.max(axis=1) - rel_end.min(axis=1))))
+                lo = np.argsort(wg_end)[-8:]
+                d.setdefault("slowest8_wg_mod8", []).append([int(v) % 8 for v in lo])
             d["issued"].extend(t[:, 1] - t[:, 0])
             if (t[:, 6] > 0).any():  # fp16 GEMV with RMSNorm: own x arrived / workgroup sum known
                 ok_ = t[:, 6] > 0
@@ -170,7 +184,12 @@ def main():
            "unit": "us; [median, p10, p90] over the waves of all launches of the class in one token (span / gap_to_next: over launches)",
            "clock": "s_memrealtime, 100 MHz (10 ns resolution)", "launches_in_token": len(launches), "classes": {}}
     for k, d in per_cls.items():
+        special = {}
+        if "xcd_mean_end" in d:  # mean end of a workgroup (us since the launch's first stamp) by XCD, and where the eight slowest workgroups of a launch sit
+            special["xcd_mean_end_us_by_xcd"] = [round(float(v), 2) for v in np.mean(np.stack(d.pop("xcd_mean_end")), axis=0)]
+            special["slowest8_workgroups_xcd_histogram"] = np.bincount(np.array(d.pop("slowest8_wg_mod8")).ravel(), minlength=8).tolist()
         out["classes"][k] = {kk: pct(v) for kk, v in d.items() if len(v)}
+        out["classes"][k].update(special)
         out["classes"][k]["launches"] = len(d["span"])
     if aw["span"]:
         def col(rows, k):
