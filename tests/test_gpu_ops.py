@@ -433,9 +433,12 @@ def test_error_paths(mgr):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19],
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 21, 22, 23, 24, 25, 26, 35, 38, 39, 42, 43, 44],
                          ids=["auto", "128x64", "128x128", "glds2", "glds3", "glds-n2", "glds-n3", "glds-n4", "glds-n3-pipe", "glds-n3-bk128", "glds-n2-bk128", "glds2-pipe",
-                              "roles-n-b6", "roles-n-b9", "roles-w-b4", "roles-w-b6"])
+                              "roles-n-b6", "roles-n-b9", "roles-w-b4", "roles-w-b6",
+                              # round 3: eight (sixteen) waves per workgroup — 256 x 128 tiles, wave groups splitting the k-steps (ks2), BK 128
+                              "256x128-w4-glds2", "256x128-w4-glds3", "256x128-w8-glds2", "256x128-w8-glds3", "128x128-ks2", "128x64-ks2", "256x128-w16-ks2",
+                              "128x128-ks2-glds4", "128x64-bk128-ks2", "128x64-ks2-glds4", "256x128-w8-glds3-pipe", "256x128-w8-glds2-pipe"])
 @pytest.mark.parametrize("M,N,K,res", [(512, 1024, 512, True), (200, 256, 384, False), (128, 384, 3072, True)])
 def test_gemm_f16_variants(mgr, variant, M, N, K, res):
     """The prefill GEMM (MatrixMultiplyShader with inputRowCount = M, which the reference never exercises) in every tile /
@@ -462,7 +465,12 @@ def test_gemm_f16_variants(mgr, variant, M, N, K, res):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [12, 13, 14, 15, 20], ids=["128x80-glds3", "128x48-glds3", "128x80-glds4", "128x48-glds4", "128x80-roles-b6"])
+@pytest.mark.parametrize("variant", [12, 13, 14, 15, 20, 27, 28, 29, 30, 31, 32, 33, 34, 36, 37, 40, 41, 45, 46, 47, 48],
+                         ids=["128x80-glds3", "128x48-glds3", "128x80-glds4", "128x48-glds4", "128x80-roles-b6",
+                              # round 3: two (four) wave groups on the tile, BK 64 / 128, deeper rings, pipelined reads, 64 x 96 tiles
+                              "128x80-ks2", "128x48-ks2", "128x48-ks2-glds4", "128x96-2x2-ks2", "128x48-ks2-glds5", "128x48-bk128-ks2", "128x48-bk128-ks4",
+                              "128x80-ks2-glds4", "128x48-ks2-glds6", "128x80-ks2-glds5", "128x80-bk128-ks2", "128x96-ks2-glds4", "128x48-bk128-ks2-pipe",
+                              "128x80-bk128-ks2-pipe", "64x96-bk128-ks2", "64x96-ks2-glds4"])
 @pytest.mark.parametrize("M,N,K,res", [(512, 960, 512, True), (200, 960, 384, False), (512, 5760, 3072, True)])
 def test_gemm_f16_odd_tile_widths(mgr, variant, M, N, K, res):
     """Tile widths 80 and 48 (exactly 256 workgroups on the 5120- and 3072-column projections at 512 rows): the B tile's
@@ -531,8 +539,8 @@ def _silu64(x):
     return x / (1.0 + np.exp(-x))
 
 
-WIDE = [0, 2, 3, 4, 11, 18, 19]     # 128 x 128 tile configurations (what gemm_pick takes for wide N at prefill sizes)
-NARROW = [1, 5, 6, 7, 8, 16, 17]    # 128 x 64
+WIDE = [0, 2, 3, 4, 11, 18, 19, 24, 25, 43]     # 128 x 128 / 256 x 128 tile configurations (what gemm_pick takes for wide N at prefill sizes)
+NARROW = [1, 5, 6, 7, 8, 16, 17, 26, 39, 42]    # 128 x 64 (the last three: two wave groups)
 
 
 @pytest.mark.gpu
