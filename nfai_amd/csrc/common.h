@@ -163,28 +163,6 @@ struct GemmRope {
 };
 hipError_t launch_rope_table(const float *freqs, uint32_t pos0, uint32_t T, uint32_t D, uint32_t rope_dims, float *cs, hipStream_t s);
 
-// RMSNorm of the prefill folded into the GEMMs on either side of it (no launch of its own).  RMSNormShader.cs:136-149 gives
-// y = (h / rms(h)) * g; the division is one scalar per ROW, so it can be applied to the finished dot products:
-//   producer (the GEMM whose output h = residual + product is normalised next; epi 0 with R): besides h (fp32) its epilogue stores
-//     u = fp16(h * g * s) — the next GEMM's A operand; s = 2^-e is a power of two taken from the row's PREVIOUS rms (the residual
-//     stream's rms moves slowly from one norm to the next), which keeps u at the magnitude of the gains whatever the activations are
-//     (fp16 overflow guard; exact, a power of two) — and the row's sum of squares over the tile's columns, ps[slot][row];
-//   consumer (epi 2 / 3): before its K loop it adds a row's partial sums in slot order (fixed order: deterministic), forms
-//     rms = sqrt(sum / E + eps), keeps 1 / (rms * s) per row in LDS and multiplies the accumulators by it in front of its epilogue;
-//     the workgroups of the first column tile store rms for the next producer's s.
-struct GemmNorm {
-    int produce = 0, consume = 0;
-    const float *gain = nullptr;      // producer: g of the norm that follows [N]
-    void *xn_out = nullptr;           // producer: u, fp16 [M][xn_ld]
-    uint32_t xn_ld = 0;
-    float *ps = nullptr;              // partial sums [slot][ps_stride]; producer writes slot = column tile, consumer reads np slots
-    uint32_t ps_stride = 0, np = 0;
-    const float *rms_prev = nullptr;  // [M]: the row's rms at the previous norm (both sides derive s from it)
-    float *rms_out = nullptr;         // consumer: rms of this norm [M]
-    uint32_t E = 0;                   // row length of the normalised vector
-    float eps = 0.f;
-};
-
 struct GemmArgs {  // C[M][N] (+R) = alpha * A[M][K] * B[N][K]^T, fp16 operands, fp32 accumulate / output
     const void *A = nullptr;   // fp16, or fp32 when a_f32 (converted while staging)
     bool a_f32 = false;
@@ -195,7 +173,6 @@ struct GemmArgs {  // C[M][N] (+R) = alpha * A[M][K] * B[N][K]^T, fp16 operands,
     int epi = 0;               // 0: fp32 (+R)   1: fp16 out   2: fp16 out = up * silu(gate), B = gate rows, B1 = up rows, N = 2F, C is [M][F]
                                // 3: RoPE + q / KV-cache stores (rope; C unused)
     GemmRope rope;
-    GemmNorm nrm;              // RMSNorm folded into this GEMM's epilogue (produce) or applied to its rows (consume); direct-to-LDS kernels only
     uint32_t n_cu = 256;
     const float *R = nullptr;  // optional residual, same layout as C (epi 0)
     uint32_t M = 0, N = 0, K = 0, lda = 0, ldb = 0, ldc = 0;
@@ -210,9 +187,7 @@ hipError_t launch_gemm_f16(const GemmArgs &a, hipStream_t s);
 hipError_t launch_gemm_kq(const GemmArgs &a, hipStream_t s);   // dequant-in-LDS GEMM on T16 K-quant weights
 hipError_t launch_f32_to_f16(const float *x, void *y_f16, uint64_t n, hipStream_t s);
 hipError_t launch_read_ahead(const void *w, uint64_t bytes, uint32_t n_cu, hipStream_t s);  // side-stream hint: the next GEMM's weights -> Infinity Cache
-hipError_t launch_rmsnorm_rows(const float *x, const float *g, void *y_f16, uint32_t T, uint32_t E, float eps, hipStream_t s, float *rms_out = nullptr);
-uint32_t gemm_norm_slots(uint32_t N);  // partial-sum slots a producer GEMM with N columns may write (upper bound over its tile widths)
-uint32_t gemm_norm_slots_used(uint32_t M, uint32_t N, uint32_t n_cu);  // ... and the number it does write for an [M][N] output
+hipError_t launch_rmsnorm_rows(const float *x, const float *g, void *y_f16, uint32_t T, uint32_t E, float eps, hipStream_t s);
 hipError_t launch_rope_store_rows(const float *q, const float *k, const float *v, void *qh_f16, void *kc, void *vc, int kv_f16,
                                   uint64_t pos_stride, uint64_t head_stride, const float *freqs, uint32_t rope_dims, uint32_t H,
                                   uint32_t Hkv, uint32_t D, uint32_t pos0, uint32_t T, uint32_t ld, void *kh_f16, void *vt_f16,

@@ -46,7 +46,6 @@ struct GemmParams {
     uint32_t causal_pos0;
     NFAI_STAMP_PARAM
     GemmRope rope;               // EPI_ROPE
-    GemmNorm nrm;                // RMSNorm folded into the GEMMs around it (common.h)
     uint32_t ksplit;             // > 1: blockIdx.z owns K tiles [z*KT/ksplit, (z+1)*KT/ksplit) and adds its product atomically
                                  // into C, which the host has initialised with the residual (or zeros)
 };
@@ -69,28 +68,12 @@ template <int CH> __device__ __forceinline__ uint32_t lds_off(uint32_t row, uint
 // act = up * silu(gate) is formed in registers and written as fp16 (SiLUShader + ElementWiseMultiplicationShader
 // fused into the GEMM: no fp32 gate/up round trip through HBM).
 // Epilogue shared by the GEMM kernels: accumulators of one wave tile -> C (fp32 + residual / fp16 / SiLU*up fp16 / split-K atomics).
-// s of GemmNorm: 2^-e with rms_prev = m * 2^e, 0.5 <= m < 1 (1 for a row without history)
-__device__ __forceinline__ float norm_pow2_scale(float rms_prev)
-{
-    int e = 0;
-    (void)frexpf(rms_prev > 0.f ? rms_prev : 1.f, &e);
-    return ldexpf(1.f, -e);
-}
-
 template <int BM, int BN, int WM, int WN, int EPI, int TM, int TN>
 __device__ __forceinline__ void gemm_store(f32x4 (&acc)[TM][TN], const GemmParams &p, uint32_t m0, uint32_t n0, uint32_t wm, uint32_t wn,
-                                           uint32_t lane, uint32_t batch, const float *inv_lds = nullptr)
+                                           uint32_t lane, uint32_t batch)
 {
     // C/D layout of mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg.
     const uint32_t rbase = m0 + wm * (BM / WM) + (lane >> 4) * 4, cbase = wn * (BN / WN) + (lane & 15);
-    if (inv_lds) {  // consumer of a folded RMSNorm: the rows' 1 / (rms * s), written to LDS before the K loop
-#pragma unroll
-        for (int i = 0; i < TM; i++) {
-            const f32x4 iv = *reinterpret_cast<const f32x4 *>(inv_lds + (rbase - m0) + i * 16);
-#pragma unroll
-            for (int j = 0; j < TN; j++) acc[i][j] *= iv;
-        }
-    }
     if constexpr (EPI == EPI_SILU) {
         _Float16 *Ch = static_cast<_Float16 *>(p.C) + (uint64_t)batch * p.c_bs;
 #pragma unroll
@@ -205,16 +188,6 @@ __device__ __forceinline__ void gemm_store(f32x4 (&acc)[TM][TN], const GemmParam
                 }
     } else {
         float *Cb = static_cast<float *>(p.C) + (uint64_t)batch * p.c_bs;
-        // producer of a folded RMSNorm: its gains and the rows' scales are requested with the residual (one round trip, not three)
-        float gn[TN], sc_prev[TM][4];
-        if (p.nrm.produce) {
-#pragma unroll
-            for (int j = 0; j < TN; j++) gn[j] = *((const GLOBAL_AS float *)p.nrm.gain + (n0 + cbase + j * 16));
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) sc_prev[i][r] = *((const GLOBAL_AS float *)p.nrm.rms_prev + min(rbase + i * 16 + r, p.M - 1));
-        }
         if (p.ksplit > 1) {  // split-K: C already holds the residual (or zeros); every split adds its share
 #pragma unroll
             for (int i = 0; i < TM; i++)
@@ -261,38 +234,6 @@ __device__ __forceinline__ void gemm_store(f32x4 (&acc)[TM][TN], const GemmParam
                     const uint32_t row = rbase + i * 16 + r, col = n0 + cbase + j * 16;
                     if (row < p.M) Cb[(uint64_t)row * p.ldc + col] = acc[i][j][r];
                 }
-        if (p.nrm.produce) {  // (block-uniform) the next GEMM's A operand and this tile's share of the rows' sums of squares
-            _Float16 *xn = static_cast<_Float16 *>(p.nrm.xn_out);
-            const uint32_t slot = (n0 / BN) * WN + wn;
-#pragma unroll
-            for (int i = 0; i < TM; i++) {
-                float sc4[4], ss4[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    sc4[r] = norm_pow2_scale(sc_prev[i][r]);
-                    ss4[r] = 0.f;
-                }
-#pragma unroll
-                for (int j = 0; j < TN; j++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const uint32_t row = rbase + i * 16 + r, col = n0 + cbase + j * 16;
-                        const float h = acc[i][j][r];
-                        ss4[r] = fmaf(h, h, ss4[r]);
-                        if (row < p.M) xn[(uint64_t)row * p.nrm.xn_ld + col] = (_Float16)((h * gn[j]) * sc4[r]);
-                    }
-#pragma unroll
-                for (int r = 0; r < 4; r++) {  // the 16 lanes of a row group hold the tile's columns of rows rbase + i * 16 + r
-                    float v = ss4[r];
-                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
-                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
-                    const uint32_t row = rbase + i * 16 + r;
-                    if ((lane & 15) == 0 && row < p.M) p.nrm.ps[(uint64_t)slot * p.nrm.ps_stride + row] = v;
-                }
-            }
-        }
     }
 }
 
@@ -797,22 +738,6 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void k_gemm_f16_glds(const GemmPar
 
     uint32_t KT = p.K / BK;
     if (p.causal == 2) KT = min(KT, (p.causal_pos0 + m0 + BM + BK - 1) / BK);
-    // consumer of a folded RMSNorm (common.h, GemmNorm): the rows' partial sums are REQUESTED here, in front of every LDS-DMA (vmcnt
-    // retires in order: they have arrived when the first tile has), and added up after the K loop — used any earlier, hipcc would wait
-    // vmcnt(0) for them, i.e. for every tile of the prologue (+2 us per GEMM, measured; as a loop of dependent round trips: +15 us).
-    // TPR neighbouring lanes per row, 64 / TPR slots each; the lanes' sums meet by DPP: a fixed tree, deterministic.
-    constexpr uint32_t TPR = (NW * 64) / BM;
-    static_assert(TPR == 1 || TPR == 2 || TPR == 4 || TPR == 8, "threads per row of the norm sums");  // (the default configurations: 2 or 4)
-    constexpr int NQ = 64 / TPR;  // np <= 64 (checked on the host)
-    float *inv_lds = reinterpret_cast<float *>(lds + (NST * A_BYTES + NSTB * B_BYTES));
-    float part[NQ], rms_prev_row = 1.f;
-    if (p.nrm.consume) {  // block-uniform
-        const uint32_t row = min(m0 + tid / TPR, p.M - 1), sub = tid % TPR;
-#pragma unroll
-        for (int q = 0; q < NQ; q++)
-            part[q] = *((const GLOBAL_AS float *)p.nrm.ps + ((uint64_t)min((uint32_t)q * TPR + sub, p.nrm.np - 1) * p.nrm.ps_stride + row));
-        rms_prev_row = *((const GLOBAL_AS float *)p.nrm.rms_prev + row);
-    }
     // prologue: tiles 0 .. depth-2 of each ring (past the end: the last tile again — the counts stay uniform)
     if constexpr (ROLES) {
         if (role_a) {
@@ -912,24 +837,6 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void k_gemm_f16_glds(const GemmPar
     }
     GEMM_TICK(c_mul);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus DMAs of the last iterations must not outlive the workgroup's LDS
-    if (p.nrm.consume) {  // 1 / (rms * s) of the tile's rows -> LDS behind the stages (read by the epilogue, behind a barrier)
-        const uint32_t rl = tid / TPR, sub = tid % TPR;
-        float tot = 0.f;
-#pragma unroll
-        for (int q = 0; q < NQ; q++) tot += ((uint32_t)q * TPR + sub < p.nrm.np) ? part[q] : 0.f;
-        if constexpr (TPR >= 2) tot += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tot), 0xB1, 0xF, 0xF, true));
-        if constexpr (TPR >= 4) tot += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tot), 0x4E, 0xF, 0xF, true));
-        if constexpr (TPR >= 8) tot += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tot), 0x141, 0xF, 0xF, true));
-        const float rms = sqrtf(tot / (float)p.nrm.E + p.nrm.eps);
-        if (sub == 0) {
-            inv_lds[rl] = 1.0f / (rms * norm_pow2_scale(rms_prev_row));
-            if (nt_i == 0 && p.nrm.rms_out && m0 + rl < p.M) p.nrm.rms_out[m0 + rl] = rms;
-        }
-        if constexpr (KS == 1) {  // (KS > 1: the barriers of the group sums below do it)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-    }
     if constexpr (KS > 1) {
         // every wave's DMAs have landed and every wave is past its last fragment read: the stages are free for the groups' sums
         static_assert((KS - 1) * BM * BN * 4 <= (NST * BM + NSTB * BN) * BK * 2, "the other groups' accumulators fit the stages");
@@ -953,7 +860,7 @@ __global__ __launch_bounds__(WM *WN *KS * 64) void k_gemm_f16_glds(const GemmPar
 #pragma unroll
                 for (int j = 0; j < TN; j++) acc[i][j] += slab[(g2 - 1) * SLAB + (i * TN + j) * 64];
     }
-    gemm_store<BM, BN, WM, WN, EPI, TM, TN>(acc, p, m0, n0, wm, wn, lane, batch, p.nrm.consume ? inv_lds : nullptr);
+    gemm_store<BM, BN, WM, WN, EPI, TM, TN>(acc, p, m0, n0, wm, wn, lane, batch);
 #ifdef NFAI_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unsigned long long c_epi = 0;
@@ -968,7 +875,7 @@ template <int BM, int BN, int WM, int WN, int EPI, int NST, int BK = 64, bool PI
 static hipError_t gemm_launch_glds(const GemmParams &p, uint32_t batch, hipStream_t s)
 {
     constexpr int NW = WM * WN * KS;
-    constexpr int LDS = (NST * BM + NSTB * BN) * BK * 2 + BM * 4;  // stages + the rows' norm factors (GemmNorm consumer)
+    constexpr int LDS = (NST * BM + NSTB * BN) * BK * 2;
     static_assert(LDS <= 160 * 1024, "LDS of one CU");
     if (p.K % BK) return hipErrorInvalidValue;
     auto kern = k_gemm_f16_glds<BM, BN, WM, WN, EPI, NST, BK, PIPE, NSTB, KS>;
@@ -989,7 +896,6 @@ template <int BM, int BN, int WM, int WN, int BK, int EPI, int KS = 1, int RING 
 static hipError_t gemm_launch(const GemmParams &p, uint32_t batch, hipStream_t s)
 {
     constexpr int LDS = 2 * (BM + BN) * BK * 2;
-    if (p.nrm.produce || p.nrm.consume) return hipErrorInvalidValue;  // the folded RMSNorm lives in the direct-to-LDS kernels only
     auto kern = k_gemm_f16<BM, BN, WM, WN, BK, EPI, KS, RING>;
     if (LDS > 64 * 1024) {
         static bool attr_set = false;
@@ -1003,25 +909,6 @@ static hipError_t gemm_launch(const GemmParams &p, uint32_t batch, hipStream_t s
     hipLaunchKernelGGL(kern, dim3(tiles, batch, p.ksplit), dim3(WM * WN * KS * 64), LDS, s, p);
     return hipGetLastError();
 }
-
-// Tile width of the narrow configuration: the one that needs the fewest rounds of workgroups over the CUs, then the fewest operand
-// bytes per workgroup (cost = rounds x (128 + BN)); NFAI_GEMM_BN forces one.
-static uint32_t pick_narrow_bn(uint32_t M, uint32_t N, uint32_t n_cu)
-{
-    static const int env_bn = getenv("NFAI_GEMM_BN") ? atoi(getenv("NFAI_GEMM_BN")) : 0;
-    const uint64_t tm = (M + 127) / 128;
-    auto cost = [&](uint32_t bn) { return ((tm * (N / bn) + n_cu - 1) / n_cu) * (128 + bn); };
-    uint32_t best = 64;
-    uint64_t best_cost = cost(64);
-    for (uint32_t bn : {48u, 80u, 96u}) {
-        if (env_bn && (uint32_t)env_bn != bn) continue;
-        if (N % bn == 0 && cost(bn) * 100 < best_cost * 97) { best = bn; best_cost = cost(bn); }
-    }
-    return best;
-}
-
-// partial-sum slots the producer GEMM of a folded RMSNorm writes for an [M][N] output (one per column tile of the narrow configuration)
-uint32_t gemm_norm_slots_used(uint32_t M, uint32_t N, uint32_t n_cu) { return N / pick_narrow_bn(M, N, n_cu ? n_cu : 256); }
 
 template <int EPI>
 static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int variant, hipStream_t s)
@@ -1142,7 +1029,14 @@ static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int va
     static const int env_bn = getenv("NFAI_GEMM_BN") ? atoi(getenv("NFAI_GEMM_BN")) : 0;
     if constexpr (EPI != EPI_SILU) {
         if (env_glds_n == 3 && p.ksplit == 1 && batch == 1 && p.causal == 0 && env_bn != 64) {
-            const uint32_t best = pick_narrow_bn(p.M, p.N, n_cu);
+            const uint64_t tm = (p.M + 127) / 128;
+            auto cost = [&](uint32_t bn) { return ((tm * (p.N / bn) + n_cu - 1) / n_cu) * (128 + bn); };
+            uint32_t best = 64;
+            uint64_t best_cost = cost(64);
+            for (uint32_t bn : {48u, 80u, 96u}) {
+                if (env_bn && (uint32_t)env_bn != bn) continue;
+                if (p.N % bn == 0 && cost(bn) * 100 < best_cost * 97) { best = bn; best_cost = cost(bn); }
+            }
             // Round 3: a second group of four waves on the same tile; the groups split every K tile's k-steps and add their
             // accumulators in LDS at the end (these launches have one workgroup per CU: the second wave per SIMD fills the first one's
             // waits).  BK = 128 where three stages fit the LDS, else four stages of 64 (3B at 512 rows: Wdown 55.3 -> 46.9 us, Wo 23.8
@@ -1195,7 +1089,12 @@ hipError_t launch_rope_table(const float *freqs, uint32_t pos0, uint32_t T, uint
 // the q | k | v projection with the RoPE epilogue: the narrow configurations only (N = (H + 2 Hkv) D is a few thousand columns)
 static hipError_t gemm_pick_rope(GemmParams &p, uint32_t n_cu, hipStream_t s)
 {
-    const uint32_t best = pick_narrow_bn(p.M, p.N, n_cu);
+    const uint64_t tm = (p.M + 127) / 128;
+    auto cost = [&](uint32_t bn) { return ((tm * (p.N / bn) + n_cu - 1) / n_cu) * (128 + bn); };
+    uint32_t best = 64;
+    uint64_t best_cost = cost(64);
+    for (uint32_t bn : {48u, 80u, 96u})
+        if (p.N % bn == 0 && cost(bn) * 100 < best_cost * 97) { best = bn; best_cost = cost(bn); }
     const bool bk128 = p.K % 128 == 0;
     if (best == 48) return bk128 ? gemm_launch_glds<128, 48, 4, 1, EPI_ROPE, 3, 128, false, 3, 2>(p, 1, s) : gemm_launch_glds<128, 48, 4, 1, EPI_ROPE, 4, 64, false, 4, 2>(p, 1, s);
     if (best == 80) return bk128 ? gemm_launch_glds<128, 80, 4, 1, EPI_ROPE, 3, 128, true, 3, 2>(p, 1, s) : gemm_launch_glds<128, 80, 4, 1, EPI_ROPE, 4, 64, false, 4, 2>(p, 1, s);
@@ -1226,13 +1125,6 @@ hipError_t launch_gemm_f16(const GemmArgs &a, hipStream_t s)
     p.causal = a.causal; p.causal_pos0 = a.causal_pos0;
     const uint32_t batch = a.batch ? a.batch : 1;
     const uint32_t n_cu = a.n_cu ? a.n_cu : 256;
-    p.nrm = a.nrm;
-    if (a.nrm.produce || a.nrm.consume) {
-        const GemmNorm &q = a.nrm;
-        if (batch != 1 || a.causal || a.variant || !q.ps || !q.rms_prev || q.ps_stride < a.M) return hipErrorInvalidValue;
-        if (q.produce && (a.epi != EPI_F32 || !a.R || !q.gain || !q.xn_out || q.xn_ld < a.N || q.consume)) return hipErrorInvalidValue;
-        if (q.consume && ((a.epi != EPI_SILU && a.epi != EPI_ROPE) || q.np == 0 || q.np > 64 || q.E == 0)) return hipErrorInvalidValue;
-    }
     if (a.epi == EPI_ROPE) {
         const GemmRope &r = a.rope;
         if (!a.B1 || !a.B2 || batch != 1 || a.R || a.causal || !r.cs || !r.qh || !r.kh || !r.vt || !r.kc || !r.vc) return hipErrorInvalidValue;
@@ -1273,7 +1165,7 @@ hipError_t launch_f32_to_f16(const float *x, void *y_f16, uint64_t n, hipStream_
 // RMSNormShader over T rows, output fp16 (the next GEMM's A operand).  One block per row; rows of up to
 // 256 * 4 * NV floats stay in registers between the two passes (16-byte loads, 8-byte fp16 stores).
 template <int NV>
-__global__ __launch_bounds__(256) void k_rmsnorm_rows_v(const float *x, const float *g, _Float16 *y, uint32_t E, float eps, float *rms_out)
+__global__ __launch_bounds__(256) void k_rmsnorm_rows_v(const float *x, const float *g, _Float16 *y, uint32_t E, float eps)
 {
     __shared__ float red[16];
     const GLOBAL_AS float *xr = (const GLOBAL_AS float *)x + (uint64_t)blockIdx.x * E;
@@ -1292,7 +1184,6 @@ __global__ __launch_bounds__(256) void k_rmsnorm_rows_v(const float *x, const fl
     }
     ss = block_sum(ss, red);
     const float rms = sqrtf(ss / (float)E + eps);
-    if (rms_out && threadIdx.x == 0) rms_out[blockIdx.x] = rms;  // history for the power-of-two scale of a folded norm (GemmNorm)
 #pragma unroll
     for (int i = 0; i < NV; i++) {
         const uint32_t k = (threadIdx.x + i * 256) * 4;
@@ -1305,7 +1196,7 @@ __global__ __launch_bounds__(256) void k_rmsnorm_rows_v(const float *x, const fl
     }
 }
 
-__global__ __launch_bounds__(256) void k_rmsnorm_rows(const float *x, const float *g, _Float16 *y, uint32_t E, float eps, float *rms_out)
+__global__ __launch_bounds__(256) void k_rmsnorm_rows(const float *x, const float *g, _Float16 *y, uint32_t E, float eps)
 {
     __shared__ float red[16];
     const float *xr = x + (uint64_t)blockIdx.x * E;
@@ -1314,26 +1205,22 @@ __global__ __launch_bounds__(256) void k_rmsnorm_rows(const float *x, const floa
     for (uint32_t i = threadIdx.x; i < E; i += blockDim.x) ss = fmaf(xr[i], xr[i], ss);
     ss = block_sum(ss, red);
     const float rms = sqrtf(ss / (float)E + eps);
-    if (rms_out && threadIdx.x == 0) rms_out[blockIdx.x] = rms;
     for (uint32_t i = threadIdx.x; i < E; i += blockDim.x) yr[i] = (_Float16)((xr[i] / rms) * g[i]);
 }
 
-hipError_t launch_rmsnorm_rows(const float *x, const float *g, void *y_f16, uint32_t T, uint32_t E, float eps, hipStream_t s, float *rms_out)
+hipError_t launch_rmsnorm_rows(const float *x, const float *g, void *y_f16, uint32_t T, uint32_t E, float eps, hipStream_t s)
 {
     _Float16 *y = static_cast<_Float16 *>(y_f16);
     if (E % 4 == 0 && E >= 4 && E <= 4096) {
-        if (E <= 1024) k_rmsnorm_rows_v<1><<<T, 256, 0, s>>>(x, g, y, E, eps, rms_out);
-        else if (E <= 2048) k_rmsnorm_rows_v<2><<<T, 256, 0, s>>>(x, g, y, E, eps, rms_out);
-        else if (E <= 3072) k_rmsnorm_rows_v<3><<<T, 256, 0, s>>>(x, g, y, E, eps, rms_out);
-        else k_rmsnorm_rows_v<4><<<T, 256, 0, s>>>(x, g, y, E, eps, rms_out);
+        if (E <= 1024) k_rmsnorm_rows_v<1><<<T, 256, 0, s>>>(x, g, y, E, eps);
+        else if (E <= 2048) k_rmsnorm_rows_v<2><<<T, 256, 0, s>>>(x, g, y, E, eps);
+        else if (E <= 3072) k_rmsnorm_rows_v<3><<<T, 256, 0, s>>>(x, g, y, E, eps);
+        else k_rmsnorm_rows_v<4><<<T, 256, 0, s>>>(x, g, y, E, eps);
     } else {
-        k_rmsnorm_rows<<<T, 256, 0, s>>>(x, g, y, E, eps, rms_out);
+        k_rmsnorm_rows<<<T, 256, 0, s>>>(x, g, y, E, eps);
     }
     return hipGetLastError();
 }
-
-// slots of ps a producer GEMM with N columns may write: its narrowest tile is 48 columns (one slot per column tile, 4 x 1 waves)
-uint32_t gemm_norm_slots(uint32_t N) { return (N + 47) / 48; }
 
 // RoPE on T rows of q (-> fp16) and k (-> KV cache rows pos0+t), v -> cache rows.  One thread per pair.
 // kh / vt (optional): the fp16 K rows [Hkv][Spad][D] and V^T [Hkv][D][Spad] the attention GEMMs read are written here

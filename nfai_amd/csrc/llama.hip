@@ -75,8 +75,6 @@ struct Model {
         uint32_t T = 0, Spad = 0;
         uint32_t *toks = nullptr;
         float *CS = nullptr;       // cos / sin of the chunk's positions [T][D/2][2] (the q | k | v epilogue)
-        float *RS = nullptr, *PS = nullptr;  // folded RMSNorm (GemmNorm): rms of the rows at the last attn / ffn norm [2][T]; partial sums [slots][T]
-        void *XN2 = nullptr;       // fp16 [T][E]: the Wo GEMM's normalised output (its own A operand lives in XN)
         float *X = nullptr, *H1 = nullptr, *Q = nullptr, *K = nullptr, *V = nullptr, *ATT = nullptr, *G = nullptr, *U = nullptr, *SC = nullptr;
         void *XN = nullptr, *QH = nullptr, *KH = nullptr, *VT = nullptr, *P = nullptr, *ACT = nullptr;  // fp16
         void *WF16 = nullptr;      // K-quant models: the blocks' matrices widened to fp16 for the MFMA GEMMs (allocated on first use) —
@@ -741,9 +739,6 @@ NFAI_API int32_t nfai_hip_llama_create(nfai_ctx_t ch, const nfai_llama_desc *des
         DALLOC(w.H1, T * d.E * 4);
         DALLOC(w.Q, T * (HD + 2 * KD) * 4);  // q | k | v columns of one GEMM output
         DALLOC(w.CS, T * d.D * 4);
-        DALLOC(w.RS, 2 * T * 4);
-        DALLOC(w.PS, (size_t)gemm_norm_slots(d.E) * T * 4);
-        DALLOC(w.XN2, T * d.E * 2);
         DALLOC(w.ATT, T * HD * 4);
         DALLOC(w.G, T * d.F * 2 * 4);        // gate | up columns of one GEMM output
         DALLOC(w.SC, (size_t)d.H * T * w.Spad * 4);
@@ -790,7 +785,7 @@ NFAI_API int32_t nfai_hip_llama_destroy(nfai_model_t h)
     void *ptrs[] = {m->d_topk, m->d_engparams, m->d_gran, m->d_epoch, m->d_engerr, m->d_pos, m->d_tok, m->d_ring, m->d_freqs, m->d_ropecs, m->d_argmax_part, m->d_attn_part, m->x, m->h,
                     m->q, m->att, m->act, m->logits, m->xn, m->qraw, m->scores, m->wts, m->proj, m->gate, m->up};
     for (void *p : ptrs) if (p) hipFree(p);
-    void *pfp[] = {m->pf.RS, m->pf.PS, m->pf.XN2, m->pf.CS, m->pf.toks, m->pf.X, m->pf.H1, m->pf.Q, m->pf.K, m->pf.V, m->pf.ATT, m->pf.G, m->pf.U, m->pf.SC,
+    void *pfp[] = {m->pf.CS, m->pf.toks, m->pf.X, m->pf.H1, m->pf.Q, m->pf.K, m->pf.V, m->pf.ATT, m->pf.G, m->pf.U, m->pf.SC,
                    m->pf.XN, m->pf.QH, m->pf.KH, m->pf.VT, m->pf.P, m->pf.ACT, m->pf.WF16};
     for (void *p : pfp) if (p) hipFree(p);
     if (m->h_pin) hipHostFree(m->h_pin);
@@ -1154,33 +1149,6 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
     const char *env_rf = getenv("NFAI_PREFILL_ROPE_FUSED");
     const bool rope_fused_ok = !(env_rf && atoi(env_rf) == 0) && d.D % 16 == 0 && d.rope_dims % 2 == 0;
     if (rope_fused_ok) P_TRY(launch_rope_table(m->d_freqs, pos0, T, d.D, d.rope_dims, w.CS, s));
-    // NFAI_PREFILL_NORM_FUSED=1 (off by default): RMSNorm folded into the GEMMs on either side of it (common.h, GemmNorm): Wo's epilogue
-    // writes the gate|up GEMM's A operand and the rows' partial sums of squares, Wdown's does the same for the next block's q|k|v; the
-    // consumers divide their rows by rms.  Only the first block's attention norm is a launch then.  fp16 GEMMs throughout (also widened
-    // K-quants) and the RoPE epilogue.  Parity-green (tests), but the four GEMMs get 1-3 us longer each (rocprofv3: +6.4 us per block
-    // against 12 us of k_rmsnorm_rows saved) and a 512-token prefill at 3B comes out 0-1 % faster, within the noise of the boxes: the
-    // default stays the two k_rmsnorm_rows launches per block, whose operand rounding is the reference's.
-    const char *env_nf = getenv("NFAI_PREFILL_NORM_FUSED");
-    bool norm_fused = env_nf && atoi(env_nf) != 0 && rope_fused_ok;
-    for (const Layer &Lc : m->layers)
-        for (const Tensor *t : {&Lc.wq, &Lc.wk, &Lc.wv, &Lc.wo, &Lc.wgate, &Lc.wup, &Lc.wdown})
-            if (t->type != NFAI_F16 && !(widen && w.WF16)) norm_fused = false;
-    const uint32_t n_cu = (uint32_t)m->ctx->prop.multiProcessorCount;
-    float *rs_attn = w.RS, *rs_ffn = w.RS + T;  // rms of the rows at the last attention / ffn norm
-    const uint32_t slots_e = gemm_norm_slots_used(T, d.E, n_cu);
-    if (slots_e > 64) norm_fused = false;  // the consumers' prologue adds at most 64 partial sums per row
-    auto set_consume = [&](GemmArgs &g, const float *rms_prev, float *rms_out) {
-        g.nrm.consume = 1; g.nrm.ps = w.PS; g.nrm.ps_stride = T; g.nrm.np = slots_e; g.nrm.rms_prev = rms_prev; g.nrm.rms_out = rms_out;
-        g.nrm.E = d.E; g.nrm.eps = d.eps;
-    };
-    auto produce_gemm = [&](const void *A, uint32_t K, const Tensor &W, float *C, const float *R, const Tensor &gain, void *xn_out,
-                            const float *rms_prev) -> hipError_t {
-        GemmArgs g;
-        g.A = A; g.lda = K; g.ldb = K; g.ldc = d.E; g.M = T; g.N = d.E; g.K = K; g.B = W.ptr; g.C = C; g.R = R; g.n_cu = n_cu;
-        g.nrm.produce = 1; g.nrm.gain = static_cast<const float *>(gain.ptr); g.nrm.xn_out = xn_out; g.nrm.xn_ld = d.E;
-        g.nrm.ps = w.PS; g.nrm.ps_stride = T; g.nrm.rms_prev = rms_prev;
-        return launch_gemm_f16(g, s);
-    };
     for (Layer &Lq : m->layers) {
         Layer L = Lq;
         if (widen && w.WF16) {
@@ -1199,9 +1167,7 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
             }
             if (w.wf16_all) w.wf16_done[li] = 1;
         }
-        const bool first_block = &Lq == &m->layers.front(), last_block = &Lq == &m->layers.back();
-        if (!norm_fused || first_block)  // (folded: the previous block's Wdown wrote XN and the partial sums)
-            P_TRY(launch_rmsnorm_rows(w.X, static_cast<const float *>(L.attn_norm.ptr), w.XN, T, d.E, d.eps, s, norm_fused ? rs_attn : nullptr));
+        P_TRY(launch_rmsnorm_rows(w.X, static_cast<const float *>(L.attn_norm.ptr), w.XN, T, d.E, d.eps, s));
         S_TRY(ahead({&L.wo}));                                                           // while q | k | v computes
         if (rope_fused_ok && L.wq.type == NFAI_F16 && L.wk.type == NFAI_F16 && L.wv.type == NFAI_F16) {
             GemmArgs g;                                                                  // q | k | v + RoPE + q / cache stores in one launch
@@ -1213,7 +1179,6 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
             g.rope.pos_stride = m->kv_pos_stride; g.rope.head_stride = m->kv_head_stride;
             g.rope.H = d.H; g.rope.Hkv = d.Hkv; g.rope.D = d.D; g.rope.rope_dims = d.rope_dims; g.rope.pos0 = pos0; g.rope.Spad = Spad;
             g.rope.kv_f16 = (uint32_t)kvf16;
-            if (norm_fused && !first_block) set_consume(g, rs_ffn, rs_attn);
             P_TRY(launch_gemm_f16(g, s));
         } else {
             P_TRY(gemm(w.XN, d.E, L.wq, &L.wk, &L.wv, w.Q, nullptr, QKV, d.E));          // q | k | v in one launch
@@ -1249,20 +1214,15 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
             }
         }
         S_TRY(ahead({&L.wgate, &L.wup}));                                                // while Wo computes
-        if (norm_fused) {  // + residual + the ffn norm's gains / sums (its division happens in the gate | up GEMM)
-            P_TRY(produce_gemm(w.XN, HD, L.wo, w.H1, w.X, L.ffn_norm, w.XN2, rs_attn));
-        } else {
-            P_TRY(gemm(w.XN, HD, L.wo, nullptr, nullptr, w.H1, w.X, d.E, HD));             // + residual (TransformerBlock.cs:153-158)
-            P_TRY(launch_rmsnorm_rows(w.H1, static_cast<const float *>(L.ffn_norm.ptr), w.XN, T, d.E, d.eps, s));
-        }
+        P_TRY(gemm(w.XN, HD, L.wo, nullptr, nullptr, w.H1, w.X, d.E, HD));                 // + residual (TransformerBlock.cs:153-158)
+        P_TRY(launch_rmsnorm_rows(w.H1, static_cast<const float *>(L.ffn_norm.ptr), w.XN, T, d.E, d.eps, s));
         S_TRY(ahead({&L.wdown}));                                                        // while gate | up computes
         {   // gate | up in one launch, act = up * silu(gate) formed in the GEMM epilogue (fp16 [T][F])
             GemmArgs g;
-            g.A = norm_fused ? w.XN2 : w.XN; g.lda = d.E; g.B = L.wgate.ptr; g.B1 = L.wup.ptr; g.n0 = d.F; g.ldb = d.E;
+            g.A = w.XN; g.lda = d.E; g.B = L.wgate.ptr; g.B1 = L.wup.ptr; g.n0 = d.F; g.ldb = d.E;
             g.C = w.ACT; g.epi = 2; g.ldc = d.F;
             g.M = T; g.N = 2 * d.F; g.K = d.E;
             g.n_cu = (uint32_t)m->ctx->prop.multiProcessorCount;
-            if (norm_fused) set_consume(g, rs_attn, rs_ffn);
             if (L.wgate.type == NFAI_F16) {
                 P_TRY(launch_gemm_f16(g, s));
             } else {
@@ -1274,10 +1234,7 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
             const Layer &N = *(&Lq + 1);
             S_TRY(ahead({&N.wq, &N.wk, &N.wv}));
         }
-        if (norm_fused && !last_block)  // + residual + the NEXT block's attention norm (gains / sums here, division in its q | k | v GEMM)
-            P_TRY(produce_gemm(w.ACT, d.F, L.wdown, w.X, w.H1, (&Lq + 1)->attn_norm, w.XN, rs_ffn));
-        else
-            P_TRY(gemm(w.ACT, d.F, L.wdown, nullptr, nullptr, w.X, w.H1, d.E, d.F));       // + residual (:176-181)
+        P_TRY(gemm(w.ACT, d.F, L.wdown, nullptr, nullptr, w.X, w.H1, d.E, d.F));           // + residual (:176-181)
     }
     if (ra_used) {  // the side stream only reads weights; the join keeps destroy / set_tensor from racing with it
         if (ra_ev >= m->pf_events.size()) {

@@ -455,7 +455,6 @@ def test_prefill_rope_in_the_gemm_epilogue_is_bit_identical(mgr, dims, n, chunk,
     w = synth.make_weights(dims, seed=72, std=0.05)
     toks = synth.make_tokens(dims, n, seed=15)
     outs = []
-    monkeypatch.setenv("NFAI_PREFILL_NORM_FUSED", "0")  # (the folded RMSNorm needs the RoPE epilogue: it would be on in one of the two runs only)
     for fused in ("1", "0"):
         monkeypatch.setenv("NFAI_PREFILL_ROPE_FUSED", fused)
         m = LlamaModel(mgr, synth.make_metadata(dims), w, 160, max_batch=chunk, kv_f16=kv16)
@@ -468,65 +467,6 @@ def test_prefill_rope_in_the_gemm_epilogue_is_bit_identical(mgr, dims, n, chunk,
     for a, b in zip(outs[0][1], outs[1][1]):
         assert np.array_equal(a, b)
     assert np.array_equal(outs[0][2], outs[1][2])
-
-
-@pytest.mark.parametrize("dims,n,chunk", [(synth.TINY_D128, 130, 128), (synth.TINY_D128, 101, 64), (synth.TINY, 37, 64)],
-                         ids=["d128-130", "d128-101-ragged-chunks", "tiny-d64"])
-def test_prefill_rmsnorm_folded_into_the_gemms(mgr, dims, n, chunk, monkeypatch):
-    """RMSNorm of the prefill without a launch of its own (NFAI_PREFILL_NORM_FUSED=1, read per call; opt-in): the GEMM in front of a norm
-    writes fp16(h * g * 2^-e) and the rows' partial sums of squares, the GEMM behind it divides its rows by rms — against the default
-    k_rmsnorm_rows launches.  The division moves from the fp16 operand to the fp32 dot product, so the two differ by
-    fp16 rounding of the operands only: logits within 1e-2 * max(1, max|logit|) of each other, same argmax, K / V rows within 2e-2, and
-    the folded form within the stated fp16 tolerance of the oracle as well."""
-    from nfai_amd.llama_model import LlamaModel
-    w = synth.make_weights(dims, seed=73, std=0.05)
-    toks = synth.make_tokens(dims, n, seed=16)
-    outs = []
-    for fused in ("1", "0"):
-        monkeypatch.setenv("NFAI_PREFILL_NORM_FUSED", fused)
-        m = LlamaModel(mgr, synth.make_metadata(dims), w, 160, max_batch=chunk)
-        lg = m.Prefill(toks)
-        kv = [m.ReadKV(l, v, pos) for l in range(dims.L) for v in (False, True) for pos in (0, chunk - 1, min(chunk, n - 1), n - 1)]
-        outs.append((lg, kv))
-        m.Dispose()
-    (a, kva), (b, kvb) = outs
-    assert np.abs(a - b).max() <= 1e-2 * max(1.0, float(np.abs(b).max())), np.abs(a - b).max()
-    assert int(np.argmax(a)) == int(np.argmax(b))
-    for x, y in zip(kva, kvb):
-        np.testing.assert_allclose(x, y, rtol=0, atol=2e-2)
-    ref = orc.OracleLlama(odesc(dims, 160), w)
-    want = None
-    for t in toks:
-        want = ref.step(int(t))
-    assert np.abs(a - want).max() <= 5e-2 * max(1.0, float(np.abs(want).max()))
-    assert int(np.argmax(a)) == orc.argmax(want)
-
-
-@pytest.mark.parametrize("dims", [synth.LLAMA_32_3B, synth.LLAMA_31_8B, synth.LLAMA_32_1B], ids=["3b", "8b", "1b"])
-def test_prefill_rmsnorm_folded_full_width_block(mgr, dims, monkeypatch):
-    """The folded RMSNorm at the published widths (one block, T = 512 in two chunks of 256: 64 / 64 / 43 partial-sum slots per row, the
-    eight-wave gate|up consumer, the q|k|v consumer with the RoPE epilogue in the second block) against
-    the oracle's token-by-token fp32 path: the stated fp16 tolerance of test_prefill_full_width_block."""
-    from dataclasses import replace
-    from nfai_amd.llama_model import LlamaModel
-    monkeypatch.setenv("NFAI_PREFILL_NORM_FUSED", "1")
-    d2 = replace(dims, L=2, V=4096, name=dims.name + "-2blk")  # two blocks: the second one's attention norm is folded into Wdown / q|k|v
-    w = synth.make_weights(d2, seed=34)
-    n, C = 512, 528
-    m = LlamaModel(mgr, synth.make_metadata(d2), w, C, max_batch=256)
-    ref = orc.OracleLlama(odesc(d2, C), w)
-    toks = synth.make_tokens(d2, n, seed=17)
-    for t in toks[:-1]:
-        ref.step(int(t), want_logits=False)
-    want = ref.step(int(toks[-1]))
-    got = m.Prefill(toks)
-    tol = 5e-2 * max(1.0, float(np.abs(want).max()))
-    assert np.abs(got - want).max() <= tol, np.abs(got - want).max()
-    assert int(np.argmax(got)) == orc.argmax(want)
-    for pos in (0, 255, 256, n - 1):
-        np.testing.assert_allclose(m.ReadKV(1, False, pos), ref.kcache(1)[pos], rtol=0, atol=2e-2)
-        np.testing.assert_allclose(m.ReadKV(1, True, pos), ref.vcache(1)[pos], rtol=0, atol=2e-2)
-    m.Dispose()
 
 
 # ---- the weight-streaming engine: one launch per block (kernels_engine.hip) ---------------------------------------------
