@@ -22,6 +22,7 @@ struct KqmParams {
     float eps;
     uint32_t K, NB, NU, UB;
     uint32_t seg6;             // NFAI_KQ_MIXED: bit i set = segment i is Q6_K (else Q4_K)
+    uint32_t rot;              // q|k|v: unit u works on tile (u + rot) mod NU
     float *y;
     const float *res;
     void *kc, *vc;
