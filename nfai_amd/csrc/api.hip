@@ -124,6 +124,25 @@ NFAI_API const char *nfai_hip_last_error(void) { return g_last_error.c_str(); }
 NFAI_API int32_t nfai_hip_abi_version(void) { return NFAI_HIP_ABI_VERSION; }
 
 // ---- context ---------------------------------------------------------------------------------
+// The context scratch backs the op-level entry points (the model object allocates its own workspaces, llama.hip).  Every user owns a
+// DISJOINT range: several of them keep ticket words that must read zero between launches, so a range shared by two users corrupts
+// the other's hand-off silently (the fused lm_head + ArgMax partials used to cover the attention tickets).
+//   [0, 4 KB)           k_argmax partials + ticket                 (nfai_hip_argmax)
+//   [4 KB, 16 KB)       fused lm_head + ArgMax partials + ticket   (nfai_hip_lmhead_argmax)
+//   [16 KB, 1 MB)       attention tickets + slice partials         (nfai_hip_attn_decode, _gemv_qkv_rope, _engine_block)
+//   [1 MB, 4 MB - 4 KB) top-k workspace                            (nfai_hip_topk)
+//   [4 MB - 4 KB, 4 MB) cos/sin table of the position | position word (last 256 bytes)
+constexpr size_t SCRATCH_BYTES = 4u << 20;
+constexpr size_t SCR_ARGMAX = 0, SCR_ARGMAX_END = 4096;
+constexpr size_t SCR_LMHEAD = 4096, SCR_LMHEAD_END = 16384;
+constexpr size_t SCR_ATTN = 16384, SCR_ATTN_END = 1u << 20;
+constexpr size_t SCR_TOPK = 1u << 20, SCR_TOPK_END = SCRATCH_BYTES - 4096;
+constexpr size_t SCR_ROPECS = SCRATCH_BYTES - 4096, SCR_POS = SCRATCH_BYTES - 256;
+static_assert(2 * ARGMAX_BLOCKS * 4 + 256 <= SCR_ARGMAX_END - SCR_ARGMAX, "k_argmax partials");
+static_assert(argmax_fused_bytes() <= SCR_LMHEAD_END - SCR_LMHEAD, "fused lm_head + ArgMax workspace");
+static_assert(SCR_ARGMAX_END <= SCR_LMHEAD && SCR_LMHEAD_END <= SCR_ATTN && SCR_ATTN_END <= SCR_TOPK && SCR_TOPK_END <= SCR_ROPECS, "scratch ranges overlap");
+static_assert(SCR_ROPECS + 3072 <= SCR_POS, "cos/sin table (<= 3072 bytes, checked by its users) runs into the position word");
+
 static int ctx_create_impl(int device, void *stream, bool own, nfai_ctx_t *out)
 {
     if (!out) return fail(NFAI_ERR_INVALID, "ctx_create: out is null");
@@ -151,7 +170,7 @@ static int ctx_create_impl(int device, void *stream, bool own, nfai_ctx_t *out)
     c->owns_stream = own;
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
-    c->scratch_bytes = 1 << 20;
+    c->scratch_bytes = SCRATCH_BYTES;
     HIP_TRY(hipMalloc(&c->scratch, c->scratch_bytes));
     HIP_TRY(hipMemset(c->scratch, 0, c->scratch_bytes));
     handle_register(c);
@@ -165,10 +184,13 @@ NFAI_API int32_t nfai_hip_ctx_create_on_stream(int32_t device, void *stream, nfa
     return ctx_create_impl(device, stream, false, out);
 }
 
+static void canary_forget_ctx(Ctx *c);  // NFAI_HIP_DEBUG_CANARY (below, with nfai_hip_buf_alloc)
+
 NFAI_API int32_t nfai_hip_ctx_destroy(nfai_ctx_t h)
 {
     CTX_OR_FAIL(c, h);
     hipStreamSynchronize(c->stream);
+    canary_forget_ctx(c);  // buffers that outlive their context must not be checked against a later context at the same address
     hipEventDestroy(c->ev0);
     hipEventDestroy(c->ev1);
     hipFree(c->scratch);
@@ -252,6 +274,18 @@ int canary_check(Buf *b, const char *when)
 }
 }  // namespace
 
+static void canary_forget_ctx(Ctx *c)
+{
+    std::lock_guard<std::mutex> lk(g_canary_mu);
+    for (size_t i = 0; i < g_canary_bufs.size();)
+        if (g_canary_bufs[i]->ctx == c) {
+            g_canary_bufs[i] = g_canary_bufs.back();
+            g_canary_bufs.pop_back();
+        } else {
+            i++;
+        }
+}
+
 static int canary_check_all(Ctx *c)
 {
     if (!canary_on()) return NFAI_OK;
@@ -278,17 +312,27 @@ NFAI_API int32_t nfai_hip_buf_alloc(nfai_ctx_t h, uint64_t bytes, nfai_buf_t *ou
         return fail(NFAI_ERR_OOM, "buf_alloc: hipMalloc(%llu) failed: %s", (unsigned long long)padded, hipGetErrorString(e));
     }
     b->ptr = static_cast<char *>(base) + guard;
+    // any failure from here on frees the allocation and the handle object; a guarded buffer is registered only once its guards
+    // (and its zero fill) are enqueued
+    hipError_t me = hipSuccess;
     if (guard) {
         b->guard_base = base;
-        HIP_TRY(hipMemsetAsync(base, CANARY_BYTE, guard, c->stream));
-        HIP_TRY(hipMemsetAsync(static_cast<char *>(b->ptr) + padded, CANARY_BYTE, guard, c->stream));
-        std::lock_guard<std::mutex> lk(g_canary_mu);
-        g_canary_bufs.push_back(b);
+        me = hipMemsetAsync(base, CANARY_BYTE, guard, c->stream);
+        if (me == hipSuccess) me = hipMemsetAsync(static_cast<char *>(b->ptr) + padded, CANARY_BYTE, guard, c->stream);
     }
-    HIP_TRY(hipMemsetAsync(b->ptr, 0, padded, c->stream));
+    if (me == hipSuccess) me = hipMemsetAsync(b->ptr, 0, padded, c->stream);
+    if (me != hipSuccess) {
+        (void)hipFree(base);
+        delete b;
+        return fail(NFAI_ERR_HIP, "buf_alloc: hipMemsetAsync failed: %s", hipGetErrorString(me));
+    }
     b->bytes = bytes;
     b->owned = true;
     b->ctx = c;
+    if (guard) {
+        std::lock_guard<std::mutex> lk(g_canary_mu);
+        g_canary_bufs.push_back(b);
+    }
     handle_register(b);
     *out = reinterpret_cast<nfai_buf_t>(b);
     return NFAI_OK;
@@ -606,7 +650,7 @@ NFAI_API int32_t nfai_hip_argmax(nfai_ctx_t h, nfai_buf_t x, uint32_t n, nfai_bu
     if (n == 0) return fail(NFAI_ERR_INVALID, "argmax: n=0");
     NEED(bx, n, 4);
     NEED(bo, 1, 4);
-    LAUNCH_TRY(launch_argmax(static_cast<const float *>(bx->ptr), n, static_cast<uint32_t *>(bo->ptr), c->scratch, nullptr,
+    LAUNCH_TRY(launch_argmax(static_cast<const float *>(bx->ptr), n, static_cast<uint32_t *>(bo->ptr), static_cast<char *>(c->scratch) + SCR_ARGMAX, nullptr,
                              nullptr, 0, c->stream));
     return NFAI_OK;
 }
@@ -652,17 +696,17 @@ NFAI_API int32_t nfai_hip_topk(nfai_ctx_t h, nfai_buf_t x, uint32_t n, float tem
     BUF_OR_FAIL(bx, x);
     if (n == 0) return fail(NFAI_ERR_INVALID, "topk: n=0");
     NEED(bx, n, 4);
-    // the upper half of the context scratch (the lower half belongs to argmax / attention, whose ticket words must stay zero)
-    if (topk_work_bytes(n) + 4096 > c->scratch_bytes / 2) return fail(NFAI_ERR_INVALID, "topk: n=%u too large for the context scratch", n);
-    return topk_run(c, static_cast<const float *>(bx->ptr), n, temperature, k, static_cast<char *>(c->scratch) + c->scratch_bytes / 2, ids_out, probs_out);
+    if (topk_work_bytes(n) > SCR_TOPK_END - SCR_TOPK) return fail(NFAI_ERR_INVALID, "topk: n=%u too large for the context scratch", n);
+    return topk_run(c, static_cast<const float *>(bx->ptr), n, temperature, k, static_cast<char *>(c->scratch) + SCR_TOPK, ids_out, probs_out);
 }
 
 // ---- fused operators -------------------------------------------------------------------------
 // Scalars the fused kernels read from device memory (so graphs can be replayed) live at the END
 // of the context scratch area when the op-level entry points are used.
-static uint32_t *scratch_pos(Ctx *c) { return reinterpret_cast<uint32_t *>(static_cast<char *>(c->scratch) + c->scratch_bytes - 256); }
-static float *scratch_ropecs(Ctx *c) { return reinterpret_cast<float *>(static_cast<char *>(c->scratch) + c->scratch_bytes - 4096); }
-static float *scratch_attn(Ctx *c) { return reinterpret_cast<float *>(static_cast<char *>(c->scratch) + 8192); }
+static uint32_t *scratch_pos(Ctx *c) { return reinterpret_cast<uint32_t *>(static_cast<char *>(c->scratch) + SCR_POS); }
+static float *scratch_ropecs(Ctx *c) { return reinterpret_cast<float *>(static_cast<char *>(c->scratch) + SCR_ROPECS); }
+static float *scratch_attn(Ctx *c) { return reinterpret_cast<float *>(static_cast<char *>(c->scratch) + SCR_ATTN); }
+static bool scratch_attn_fits(uint32_t H, uint32_t Hkv, uint32_t D) { return attn_partials_bytes(H, Hkv, D) <= SCR_ATTN_END - SCR_ATTN; }
 
 NFAI_API int32_t nfai_hip_attn_decode(nfai_ctx_t h, nfai_buf_t q, nfai_buf_t kc, nfai_buf_t vc, nfai_buf_t o, uint32_t H,
                                       uint32_t Hkv, uint32_t D, uint32_t S, uint32_t C, int32_t kv_type)
@@ -679,7 +723,7 @@ NFAI_API int32_t nfai_hip_attn_decode(nfai_ctx_t h, nfai_buf_t q, nfai_buf_t kc,
     NEED(bk, (uint64_t)S * Hkv * D, esz);
     NEED(bv, (uint64_t)S * Hkv * D, esz);
     NEED(bo, (uint64_t)H * D, 4);
-    if (attn_partials_bytes(H, Hkv, D) + 8192 + 4096 > c->scratch_bytes) return fail(NFAI_ERR_INVALID, "attn_decode: H*D too large for scratch");
+    if (!scratch_attn_fits(H, Hkv, D)) return fail(NFAI_ERR_INVALID, "attn_decode: H*D too large for scratch");
     const uint32_t pos = S - 1;
     HIP_TRY(hipMemcpyAsync(scratch_pos(c), &pos, 4, hipMemcpyHostToDevice, c->stream));
     AttnArgs a;
@@ -871,8 +915,8 @@ NFAI_API int32_t nfai_hip_lmhead_argmax(nfai_ctx_t h, nfai_buf_t W, int32_t type
     a.K = E;
     a.mode = GEMV_PLAIN;
     a.y = static_cast<float *>(by->ptr);
-    // workspace: the context scratch behind k_argmax's partials (ticket word zero between launches)
-    a.argmax_part = static_cast<char *>(c->scratch) + 4096;
+    // workspace: its own range of the context scratch (ticket word zero between launches)
+    a.argmax_part = static_cast<char *>(c->scratch) + SCR_LMHEAD;
     a.argmax_out = static_cast<uint32_t *>(bo->ptr);
     return gemv_common(c, a, __func__);
 }

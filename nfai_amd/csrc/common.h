@@ -296,6 +296,7 @@ size_t topk_work_bytes(uint32_t n);
 size_t topk_out_offset();
 hipError_t launch_topk(const float *x, uint32_t n, float temperature, uint32_t k, void *work, hipStream_t s);
 // launch + 8k + 8 bytes back + the host half (api.hip); blocking
+void topk_finish(const float *vals, const uint32_t *ids, float M, float S, float temperature, uint32_t k, uint32_t *ids_out, float *probs_out);
 int topk_run(Ctx *c, const float *logits_dev, uint32_t n, float temperature, uint32_t k, void *work, uint32_t *ids_out, float *probs_out);
 // per-token prologue: embed row -> x, cos/sin table for the current position
 hipError_t launch_token_begin(const void *table, int type, const uint32_t *tok, float *x, uint32_t E,

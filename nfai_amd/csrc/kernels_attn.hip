@@ -29,6 +29,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include <mutex>
 
 namespace nfai {
 
@@ -710,13 +711,19 @@ size_t attn_wo_extra_bytes(uint32_t H, uint32_t D) { return (size_t)H * D * size
 template <typename K>
 static bool grid_resident(K kernel, uint32_t threads, size_t lds, uint32_t blocks, uint32_t n_cu)
 {
-    static size_t memo_lds = ~(size_t)0;  // per kernel instantiation: the last answer (the LDS size only changes with the KV capacity)
+    // per kernel instantiation: the last answer, keyed by (device, threads, LDS size — which only changes with the KV capacity).
+    // Contexts on different threads share the memo, hence the lock (a launch path, taken once per enqueue, not per kernel).
+    static std::mutex mu;
+    static size_t memo_lds = ~(size_t)0;
     static uint32_t memo_threads = 0;
-    static int memo_per_cu = 0;
-    if (memo_lds != lds || memo_threads != threads) {
+    static int memo_per_cu = 0, memo_dev = -1;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    std::lock_guard<std::mutex> lk(mu);
+    if (memo_lds != lds || memo_threads != threads || memo_dev != dev) {
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)threads, lds) != hipSuccess) { (void)hipGetLastError(); return false; }
-        memo_per_cu = per_cu; memo_lds = lds; memo_threads = threads;
+        memo_per_cu = per_cu; memo_lds = lds; memo_threads = threads; memo_dev = dev;
     }
     return memo_per_cu > 0 && (uint64_t)memo_per_cu * n_cu >= blocks;
 }

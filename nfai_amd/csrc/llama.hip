@@ -1006,10 +1006,44 @@ NFAI_API int32_t nfai_hip_llama_decode_topk(nfai_model_t h, uint32_t token, floa
     NEED_FINAL(m);
     if (!(m->first_stage && m->last_stage)) return fail(NFAI_ERR_STATE, "decode_topk: model is a pipeline stage");
     if (token >= m->d.V) return fail(NFAI_ERR_INVALID, "decode_topk: token %u >= vocab %u", token, m->d.V);
+    // every argument is checked BEFORE the token runs (topk_run's own predicates): a rejected call leaves the position where it was
+    if (!ids_out || !probs_out) return fail(NFAI_ERR_INVALID, "decode_topk: null output");
+    if (k == 0 || k > TOPK_MAX || k > m->d.V) return fail(NFAI_ERR_INVALID, "decode_topk: k=%u outside [1, min(%u, V=%u)]", k, TOPK_MAX, m->d.V);
+    if (!(temperature > 0.f)) return fail(NFAI_ERR_INVALID, "decode_topk: temperature %g (the reference divides by it, SamplingUtils.cs:7)", temperature);
     if (!m->d_topk) DALLOC(m->d_topk, topk_work_bytes(m->d.V));
-    int rc = step_blocking(m, token);
+    // the token's graph, the candidate launch and ONE read-back (error word + 8 * TOPK_MAX + 8 bytes) behind each other on the stream:
+    // one host synchronisation per sampled token
+    hipStream_t s = m->ctx->stream;
+    const uint32_t pos = m->pos_host;
+    int rc = set_token_async(m, token);
     if (rc) return rc;
-    return topk_run(m->ctx, m->logits, m->d.V, temperature, k, m->d_topk, ids_out, probs_out);
+    if ((rc = run_token(m))) return rc;
+    struct TopkOut { float v[TOPK_MAX]; uint32_t i[TOPK_MAX]; float M, S; };
+    static_assert(sizeof(TopkOut) + 16 <= 4096, "pinned staging");
+    TopkOut *out = reinterpret_cast<TopkOut *>(m->h_pin + 4);
+    hipError_t e = launch_topk(m->logits, m->d.V, temperature, k, m->d_topk, s);
+    if (e != hipSuccess) return fail(NFAI_ERR_HIP, "decode_topk: launch failed: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpyAsync(m->h_pin + 1, m->d_engerr, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out, static_cast<const char *>(m->d_topk) + topk_out_offset(), sizeof(TopkOut), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (m->h_pin[1] != 0) {
+        // a bounded wait of the attention hand-off gave up: step_blocking's recovery (ticket form, same token again), then the candidates
+        const uint32_t code = m->h_pin[1];
+        if (m->attn_ticket || (code & ~0x7000u) != 0) return engine_failed(m, code);
+        fprintf(stderr, "nfai_hip: an attention launch gave up waiting for a KV slice's partial results (code 0x%x) at position %u; re-running "
+                        "the token on the ticket hand-off, which this model keeps from now on.\n", code, pos);
+        m->attn_ticket = true;
+        drop_graphs(m);
+        HIP_TRY(hipMemsetAsync(m->d_engerr, 0, 4, s));
+        HIP_TRY(hipMemcpyAsync(m->d_pos, &pos, 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        m->h_pin[1] = 0;
+        m->pos_host = pos;
+        if ((rc = step_blocking(m, token))) return rc;
+        return topk_run(m->ctx, m->logits, m->d.V, temperature, k, m->d_topk, ids_out, probs_out);
+    }
+    topk_finish(out->v, out->i, out->M, out->S, temperature, k, ids_out, probs_out);
+    return NFAI_OK;
 }
 
 NFAI_API int32_t nfai_hip_llama_set_token(nfai_model_t h, uint32_t token)

@@ -340,6 +340,54 @@ def test_attn_decode_online_softmax_spike(mgr):
     np.testing.assert_allclose(po.GetValue()[:D], Vc[555, :D], rtol=0, atol=1e-3)  # head 0 ~ one-hot on t=555
 
 
+def test_scratch_users_do_not_share_ranges(mgr):
+    """the op-level entry points keep ticket words in the context scratch; lm_head + ArgMax (large winning row indices
+    at V = 128,256), the ticket form of the fused attention (8B head shape, 32 slices at S >= 1024), the plain ArgMax and the
+    top-k launch interleaved on ONE context must each stay exact — their workspaces are disjoint ranges now."""
+    import ctypes as Cc
+    from nfai_amd import _lib
+    from nfai_amd._lib import call
+    from nfai_amd.hip import ShaderProperty
+    r = rng(2024)
+    V, E = 128256, 256
+    base = (0.02 * r.standard_normal((4096, E))).astype(np.float16)
+    W = np.tile(base, ((V + 4095) // 4096, 1))[:V].copy()
+    x = r.standard_normal(E).astype(np.float32)
+    W[V - 5] = (np.sign(x) * 0.05).astype(np.float16)          # the winner sits in the last workgroups: large partial indices
+    tab = mgr.UploadWeight(1, W, V, E)
+    px, pl, pi = ShaderProperty(mgr, E), ShaderProperty(mgr, V), ShaderProperty(mgr, 1, np.uint32)
+    px.SetValue(x)
+    H, Hkv, D, S, C = 32, 8, 128, 1500, 2048
+    q = r.standard_normal(H * D).astype(np.float32)
+    Kc = r.standard_normal((C, Hkv * D)).astype(np.float32)
+    Vc = r.standard_normal((C, Hkv * D)).astype(np.float32)
+    pq, po = ShaderProperty(mgr, H * D), ShaderProperty(mgr, H * D)
+    pk, pv = ShaderProperty(mgr, C * Hkv * D), ShaderProperty(mgr, C * Hkv * D)
+    pq.SetValue(q); pk.SetValue(Kc); pv.SetValue(Vc)
+    att_ref = orc.attn_wsum(orc.attn_softmax(orc.attn_scores(q, Kc, H, Hkv, D, S)), Vc, H, Hkv, D, S)
+    k = 40
+    ids, probs = np.empty(k, np.uint32), np.empty(k, np.float32)
+    for rep in range(3):
+        call("nfai_hip_lmhead_argmax", mgr.handle, tab.handle, 1, px.handle, 0, 1e-5, pl.handle, pi.handle, V, E)
+        lg = pl.GetValue()
+        assert int(pi.GetValue()[0]) == V - 5 == int(np.argmax(lg))
+        po.SetValue(np.zeros(H * D, np.float32))
+        call("nfai_hip_attn_decode", mgr.handle, pq.handle, pk.handle, pv.handle, po.handle, H, Hkv, D, S, C, _lib.F32)
+        np.testing.assert_allclose(po.GetValue(), att_ref, rtol=0, atol=3e-5)
+        pi.SetValue(np.zeros(1, np.uint32))
+        call("nfai_hip_lmhead_argmax", mgr.handle, tab.handle, 1, px.handle, 0, 1e-5, pl.handle, pi.handle, V, E)
+        assert int(pi.GetValue()[0]) == V - 5
+        call("nfai_hip_topk", mgr.handle, pl.handle, V, 0.5, k, ids.ctypes.data_as(Cc.POINTER(Cc.c_uint32)), probs.ctypes.data_as(Cc.POINTER(Cc.c_float)))
+        _, ids_ref, probs_ref, _ = orc.topp(lg, 0.5, 0.95, k, 0.0)
+        np.testing.assert_array_equal(ids, ids_ref)
+        np.testing.assert_allclose(probs, probs_ref, rtol=1e-6)
+        call("nfai_hip_argmax", mgr.handle, pl.handle, V, pi.handle)
+        assert int(pi.GetValue()[0]) == V - 5
+        po.SetValue(np.zeros(H * D, np.float32))
+        call("nfai_hip_attn_decode", mgr.handle, pq.handle, pk.handle, pv.handle, po.handle, H, Hkv, D, S, C, _lib.F32)
+        np.testing.assert_allclose(po.GetValue(), att_ref, rtol=0, atol=3e-5)
+
+
 @pytest.mark.parametrize("E,N", [(2048, 2048), (3072, 3072), (4096, 1024), (256, 96)])
 def test_gemv_fused_norm_residual(mgr, E, N):
     from nfai_amd import _lib
