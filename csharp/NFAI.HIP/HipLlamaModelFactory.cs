@@ -50,6 +50,13 @@ public sealed unsafe class HipLlamaModel : IInferenceProvider
 
     public string ModelName { get; init; }
     public bool Greedy { get; set; }
+    /// <summary>true (default): RunAsync hands every prompt token but the last to nfai_hip_llama_ingest — the batched MFMA prefill in
+    /// chunks of PromptChunk tokens (fp16 operands on the matrix cores: the cache rows agree with the token-by-token path to the
+    /// stated fp16 tolerance, INTEGRATION.md 3).  false: one nfai_hip_llama_decode_step per prompt token, bit for bit the M = 1 path
+    /// the reference runs (LlamaModel.cs:103-126) — for parity runs.</summary>
+    public bool PromptPrefill { get; set; } = true;
+    /// <summary>Tokens per prefill chunk = nfai_llama_desc.max_batch (the MFMA workspace is allocated for this many rows).</summary>
+    public const uint PromptChunk = 512;
 
     public HipLlamaModel(HipBufferManager bufferManager, Dictionary<string, object> metadata, List<AbstractComputeCollection> tensors,
                          uint contextSize = 1024u, LlamaFlags flags = LlamaFlags.None, bool referenceRopeTable = true)
@@ -74,7 +81,7 @@ public sealed unsafe class HipLlamaModel : IInferenceProvider
             // TransformerBlock.cs:66 uploads 32 frequencies whatever the head size (reference-exact); ropeDimensions / 2 = spec-correct
             RopeNFreqs = referenceRopeTable ? Math.Min(32u, ropeDimensions / 2) : ropeDimensions / 2,
             LayerBegin = 0, LayerEnd = (uint)metadata["llama.block_count"],
-            Flags = (uint)flags, MaxBatch = 0,
+            Flags = (uint)flags, MaxBatch = Math.Min(contextSize, PromptChunk),
         };
         Native.Check(Native.nfai_hip_llama_create(bufferManager.Ctx, in desc, out model));
         try
@@ -114,12 +121,24 @@ public sealed unsafe class HipLlamaModel : IInferenceProvider
         }
     }
 
-    /// <summary>≙ RunAsync (LlamaModel.cs:99-174): the prompt token by token, then sample / feed back until EOS.</summary>
+    /// <summary>≙ RunAsync (LlamaModel.cs:99-174): the prompt, then sample / feed back until EOS.  The reference runs every prompt
+    /// token through the M = 1 path and keeps only the last token's logits (:103-130); here the tokens in front of the last one
+    /// go through ONE native call that fills the KV cache on the MFMA prefill path (PromptPrefill), the last one through the
+    /// sampled step.</summary>
     public async IAsyncEnumerable<string> RunAsync(string prompt, [EnumeratorCancellation] CancellationToken ct = default)
     {
         var tokenIds = tokenizer.Tokenize(prompt, addBos: firstInput);                          // :101
         firstInput = false;
-        for (int i = 0; i + 1 < tokenIds.Count; i++) Step(tokenIds[i], sample: false);          // :103-126 (only the last output is sampled)
+        if (PromptPrefill && tokenIds.Count > 1)                                                // :103-126 (only the last output is sampled)
+        {
+            var head = tokenIds.Take(tokenIds.Count - 1).ToArray();
+            fixed (uint* p = head)
+                Native.Check(Native.nfai_hip_llama_ingest(model, p, (uint)head.Length));        // NFAI_ERR_KV_FULL before anything runs
+        }
+        else
+        {
+            for (int i = 0; i + 1 < tokenIds.Count; i++) Step(tokenIds[i], sample: false);
+        }
         var tk = Step(tokenIds[^1], sample: true);                                              // :128-130
         yield return tokenizer.Detokenize([tk]);
         while (tk != tokenizer.EosTokenId && !ct.IsCancellationRequested)                       // :134-173

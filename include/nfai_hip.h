@@ -270,6 +270,14 @@ int32_t nfai_hip_llama_fetch_tokens(nfai_model_t model, uint32_t n, uint32_t *to
  * until a tensor is replaced) when all of them fit a quarter of the device's memory, else one block's scratch is re-widened
  * per block (NFAI_PREFILL_WIDE_ALL=0 / 1 forces either); the decode path always streams the quantised blocks. */
 int32_t nfai_hip_llama_prefill(nfai_model_t model, const uint32_t *tokens, uint32_t n, float *logits_last_host);
+/* The prompt phase of LlamaModel.RunAsync (LlamaModel.cs:103-126 feeds tokenIds one by one and keeps only the LAST token's logits,
+ * :128-130): n tokens at positions pos..pos+n-1 leave their K / V rows in the cache, nothing is sampled and no logits are formed
+ * (no output norm, no lm_head).  The caller then runs the last prompt token through _decode_step / _decode_topk, whose output IS
+ * sampled.  Same engine as _prefill: the MFMA path in chunks of desc.max_batch tokens when the model was created with max_batch > 0
+ * (fp16 operands: the cache rows agree with the token-by-token path to the fp16 tolerance, 2e-2 absolute on unit-scale rows), the
+ * M = 1 path token by token otherwise (bit-identical to _decode_step).  n == 0 is a no-op.  NFAI_ERR_KV_FULL when pos + n exceeds
+ * the KV capacity, before anything runs.  Blocking. */
+int32_t nfai_hip_llama_ingest(nfai_model_t model, const uint32_t *tokens, uint32_t n);
 /* Pipeline stage: run this stage's blocks on a hidden state resident in device memory.
  * First stage: hidden_in == NULL and `token` is embedded.  Last stage: lm_head + argmax run and
  * `logits_host`/`argmax` are filled (blocking) when non-NULL.  Otherwise enqueue only. */

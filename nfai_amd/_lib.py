@@ -100,6 +100,7 @@ SIGNATURES = {
     "nfai_hip_llama_set_token": [H, u32],
     "nfai_hip_llama_fetch_tokens": [H, u32, C.POINTER(u32)],
     "nfai_hip_llama_prefill": [H, C.POINTER(u32), u32, C.POINTER(f32)],
+    "nfai_hip_llama_ingest": [H, C.POINTER(u32), u32],
     "nfai_hip_llama_stage_step": [H, u32, vp, vp, C.POINTER(f32), C.POINTER(u32)],
     "nfai_hip_llama_token_to_device": [H, vp],
     "nfai_hip_llama_token_from_device": [H, vp],

@@ -1303,7 +1303,8 @@ static bool prefill_mfma_ok(const Model *m)
     return true;
 }
 
-NFAI_API int32_t nfai_hip_llama_prefill(nfai_model_t h, const uint32_t *tokens, uint32_t n, float *logits_last_host)
+// head = false: only the KV cache is filled (nfai_hip_llama_ingest: prompt tokens whose output the reference's loop discards).
+static int prefill_impl(nfai_model_t h, const uint32_t *tokens, uint32_t n, float *logits_last_host, bool head)
 {
     MODEL_OR_FAIL(m, h);
     NEED_FINAL(m);
@@ -1354,7 +1355,7 @@ NFAI_API int32_t nfai_hip_llama_prefill(nfai_model_t h, const uint32_t *tokens, 
     }
     // logits of the LAST prompt token: output norm + lm_head + argmax on its hidden state.  The
     // position was already advanced past the prompt, so the head runs without the token bookkeeping.
-    {
+    if (head) {
         Rec rec{m};
         const Tensor &head = m->output.ptr ? m->output : m->token_embd;
         GemvArgs a = gemv_base(m, head, m->x, m->d.E);
@@ -1368,9 +1369,22 @@ NFAI_API int32_t nfai_hip_llama_prefill(nfai_model_t h, const uint32_t *tokens, 
         K_TRY(KC_LMHEAD, launch_gemv(a, s));
         if (!am_fused) K_TRY(KC_OTHER, launch_argmax(m->logits, m->d.V, m->d_tok, m->d_argmax_part, nullptr, nullptr, 0, s));
     }
-    if (logits_last_host) HIP_TRY(hipMemcpyAsync(logits_last_host, m->logits, (size_t)m->d.V * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    if (head && logits_last_host) HIP_TRY(hipMemcpyAsync(logits_last_host, m->logits, (size_t)m->d.V * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));  // `tokens` is the caller's (pageable) memory: the copy into the workspace has left it by now
     return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_llama_prefill(nfai_model_t h, const uint32_t *tokens, uint32_t n, float *logits_last_host)
+{
+    return prefill_impl(h, tokens, n, logits_last_host, true);
+}
+
+// The prompt phase of LlamaModel.RunAsync (LlamaModel.cs:103-126): every prompt token but the last only has to leave its K and V
+// rows behind — the loop overwrites the logits of token i with those of token i + 1 and samples once, after the last one (:128-130).
+NFAI_API int32_t nfai_hip_llama_ingest(nfai_model_t h, const uint32_t *tokens, uint32_t n)
+{
+    if (n == 0) return NFAI_OK;   // a one-token prompt has nothing in front of the sampled step
+    return prefill_impl(h, tokens, n, nullptr, false);
 }
 
 // The stage's work for one token: hidden state in -> this stage's blocks -> hidden state out

@@ -113,8 +113,12 @@ class LlamaModel:
                  tokenizer=None, unfused: bool = False, graph: bool = True, kv_f16: bool = False,
                  rope_n_freqs: int | None = None, rope_base: float | None = 500000.0,
                  layer_range: tuple[int, int] | None = None, dims: dict | None = None, max_batch: int = 0,
-                 share_from: "LlamaModel | None" = None, engine: bool | None = None):
+                 share_from: "LlamaModel | None" = None, engine: bool | None = None, prompt_prefill: bool = True):
         self.mgr = mgr
+        # RunAsync's prompt phase: True = all prompt tokens but the last through nfai_hip_llama_ingest (the batched MFMA prefill when
+        # the model was created with max_batch > 0); False = token by token through the M = 1 path, bit for bit what the decode
+        # path computes (parity runs against the reference's loop, LlamaModel.cs:103-126)
+        self.promptPrefill = bool(prompt_prefill)
         d = dims or dims_from_metadata(metadata, tensors)
         self.dims = d
         self.ModelName = str(metadata.get("general.name", "unknown"))
@@ -198,6 +202,12 @@ class LlamaModel:
              logits.ctypes.data_as(C.POINTER(C.c_float)) if want_logits else None)
         return logits
 
+    def Ingest(self, tokens) -> None:
+        """Prompt tokens whose output is never sampled (LlamaModel.cs:103-126 keeps only the last token's logits): K / V rows only."""
+        t = np.ascontiguousarray(tokens, np.uint32)
+        if t.size:
+            call("nfai_hip_llama_ingest", self.handle, t.ctypes.data_as(C.POINTER(C.c_uint32)), t.size)
+
     def StageStep(self, token: int = 0, hidden_in: int | None = None, hidden_out: int | None = None, want_logits: bool = False,
                   want_argmax: bool = False):
         logits = np.empty(self.dims["V"], np.float32) if want_logits else None
@@ -267,8 +277,14 @@ class LlamaModel:
                 return self.Step(tok, want_logits=False)[1]
             ids, probs = self.StepTopK(tok)
             return SamplingUtils.TopPFromCandidates(ids, probs, rng=rng)
-        for tok in tokenIds[:-1]:  # prompt, one token at a time (:103-126); only the last token's output is sampled (:128-130)
-            self.Step(tok, want_logits=False)
+        # prompt (:103-126): only the last token's output is sampled (:128-130), so the tokens in front of it only have to fill the
+        # KV cache — ONE call, the MFMA prefill in chunks of max_batch (fp16 operands; INTEGRATION.md 3 states the precision trade);
+        # promptPrefill = False feeds them one at a time as the reference does
+        if self.promptPrefill:
+            self.Ingest(tokenIds[:-1])
+        else:
+            for tok in tokenIds[:-1]:
+                self.Step(tok, want_logits=False)
         tk = step(tokenIds[-1])
         yield self.tokenizer.Detokenize([tk])
         n = 1
@@ -290,9 +306,13 @@ class LlamaModelFactory:
     def __init__(self, device: int = 0):
         self.mgr = HipBufferManager(device)
 
+    PROMPT_CHUNK = 512  # tokens per MFMA prefill chunk of the provider path (workspace ~ 60 KB per token at 3B)
+
     def TryCreate(self, metadata: dict, tensors: dict, modelOptions: ModelOptions, **kw):
         if str(metadata.get("general.architecture", "")) != "llama":
             return False, None
+        # the provider path ingests prompts through the MFMA prefill: give the model its workspace unless the caller decides otherwise
+        kw.setdefault("max_batch", min(int(modelOptions.KVCacheSize), self.PROMPT_CHUNK))
         return True, LlamaModel(self.mgr, metadata, tensors, modelOptions.KVCacheSize, **kw)
 
     def Dispose(self) -> None:

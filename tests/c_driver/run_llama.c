@@ -3,7 +3,8 @@
  *
  * It plays LlamaModelFactory.TryCreate + LlamaModel.RunAsync (LlamaModelFactory.cs:24-44, LlamaModel.cs:99-174): create the
  * context, describe the model, hand every GGUF-named tensor over in its on-disk encoding (fp16 matrices, fp32 gains), feed a
- * prompt token by token, then sample greedily and feed back (SamplingUtils.ArgMax, SamplingUtils.cs:43-57).  The same loop
+ * prompt token by token — and, in a later pass, through nfai_hip_llama_ingest as the drop-in's RunAsync does — then sample greedily
+ * and feed back (SamplingUtils.ArgMax, SamplingUtils.cs:43-57).  The same loop
  * runs on the CPU oracle (oracle/libnfai_oracle.so: TEST INFRASTRUCTURE, linked by this test driver only) with the same
  * weights; logits must agree within the end-to-end tolerance of tests/test_gpu_model.py and the tokens must be identical.
  * A second pass uses the device-side greedy loop (nfai_hip_llama_decode_greedy) and must reproduce the tokens.
@@ -84,7 +85,8 @@ int main(void)
     memset(&d, 0, sizeof d);
     d.E = E; d.L = L; d.H = H; d.Hkv = Hkv; d.D = D; d.F = F; d.V = V; d.C = C;
     d.eps = 1e-5f; d.rope_base = 500000.0f; d.rope_dims = D; d.rope_n_freqs = D / 2;
-    d.layer_begin = 0; d.layer_end = L; d.flags = 0; d.max_batch = 0;
+    d.layer_begin = 0; d.layer_end = L; d.flags = 0;
+    d.max_batch = 4;   /* MFMA prefill workspace: the 7 prompt tokens in front of the sampled one go in two chunks (4 + 3) */
     nfai_model_t model;
     CHECK(nfai_hip_llama_create(ctx, &d, &model));
 
@@ -125,6 +127,7 @@ int main(void)
     const uint32_t prompt[] = {5, 17, 300, 44, 9, 701, 2, 63};
     const uint32_t n_prompt = sizeof prompt / sizeof prompt[0], n_gen = 40;
     float *lg = malloc(V * 4), *lr = malloc(V * 4);
+    float *lr_first = malloc(V * 4);   /* the oracle's logits of the last prompt token = of the first sampled step */
     uint32_t tokens[64], am = 0, bad = 0;
     double worst = 0.0;
     for (uint32_t i = 0; i < n_prompt + n_gen; i++) {
@@ -139,6 +142,7 @@ int main(void)
         if (maxd / maxabs > worst) worst = maxd / maxabs;
         if (maxd > 2e-3f * maxabs || am != orc_argmax(lr, V)) bad++;   /* tests/test_gpu_model.py: logit_tol */
         if (i >= n_prompt) tokens[i - n_prompt] = tok;
+        if (i + 1 == n_prompt) memcpy(lr_first, lr, V * 4);
     }
     uint32_t pos = 0;
     CHECK(nfai_hip_llama_pos(model, &pos));
@@ -156,6 +160,35 @@ int main(void)
     for (uint32_t k = 0; k < n_gen; k++)
         if (dev_tokens[k] != tokens[k]) { fprintf(stderr, "device greedy loop differs at %u: %u vs %u\n", k, dev_tokens[k], tokens[k]); return 1; }
     printf("device greedy loop: %u tokens identical\n", n_gen);
+
+    /* RunAsync as the drop-in runs it (HipLlamaModel.RunAsync, nfai_amd.llama_model.LlamaModel.RunAsync): the prompt tokens in front
+     * of the last one in ONE call on the MFMA prefill path (nfai_hip_llama_ingest: K / V rows only, fp16 operands), the last prompt
+     * token through the sampled step, then the device-side greedy loop.  Stated fp16 tolerance on the first sampled step's logits
+     * (5e-2 * max(1, max|logit|), tests/test_gpu_model.py::test_prefill_mfma_matches_token_by_token), identical greedy tokens. */
+    CHECK(nfai_hip_llama_reset(model));
+    CHECK(nfai_hip_llama_ingest(model, prompt, n_prompt - 1));
+    CHECK(nfai_hip_llama_pos(model, &pos));
+    if (pos != n_prompt - 1) { fprintf(stderr, "ingest: position %u, expected %u\n", pos, n_prompt - 1); return 1; }
+    CHECK(nfai_hip_llama_decode_step(model, prompt[n_prompt - 1], lg, &am));
+    {
+        float maxabs = 1.0f, maxd = 0.f;
+        for (uint32_t v = 0; v < V; v++) {
+            if (fabsf(lr_first[v]) > maxabs) maxabs = fabsf(lr_first[v]);
+            if (fabsf(lg[v] - lr_first[v]) > maxd) maxd = fabsf(lg[v] - lr_first[v]);
+        }
+        printf("prompt through nfai_hip_llama_ingest (MFMA prefill, 4 + 3 tokens): first sampled step max|dlogit| = %.3g (tolerance %.3g)\n",
+               maxd, 5e-2f * maxabs);
+        if (maxd > 5e-2f * maxabs || am != tokens[0]) { fprintf(stderr, "ingest path: first sampled token %u vs %u\n", am, tokens[0]); return 1; }
+    }
+    CHECK(nfai_hip_llama_decode_greedy(model, am, n_gen - 1, dev_tokens));
+    for (uint32_t k = 0; k + 1 < n_gen; k++)
+        if (dev_tokens[k] != tokens[k + 1]) { fprintf(stderr, "ingest path: greedy token %u differs: %u vs %u\n", k + 1, dev_tokens[k], tokens[k + 1]); return 1; }
+    printf("ingest path: %u greedy tokens identical to the token-by-token run\n", n_gen);
+    /* a prompt that does not fit is refused before anything runs (the reference overruns its cache, MatrixMultiplyShader.cs:248-252) */
+    CHECK(nfai_hip_llama_set_pos(model, C - 3));
+    if (nfai_hip_llama_ingest(model, prompt, n_prompt - 1) != NFAI_ERR_KV_FULL) { fprintf(stderr, "ingest: expected NFAI_ERR_KV_FULL\n"); return 1; }
+    CHECK(nfai_hip_llama_pos(model, &pos));
+    if (pos != C - 3) { fprintf(stderr, "ingest: a refused call moved the position to %u\n", pos); return 1; }
 
     /* the reference's DEFAULT sampler (LlamaModel.cs:128-130: SamplingUtils.TopP on the logits it reads back): the candidates come
      * from the device (nfai_hip_llama_decode_topk), the nucleus cut and the draw are the host's — SamplingUtils.cs:14-31 restated */

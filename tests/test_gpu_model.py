@@ -369,13 +369,22 @@ def test_gguf_file_to_generation_end_to_end(mgr, tmp_path):
 
     model = gguf.Parser([Factory(mgr)]).Parse(ModelOptions(GGUFPath=path, KVCacheSize=128))
     assert model.ModelName == dims.name and model.C == 128
+    # the factory gives the provider path its MFMA prefill workspace: RunAsync ingests the prompt (all tokens but the last) in ONE
+    # call (nfai_hip_llama_ingest), the last prompt token goes through the sampled step
+    assert model.promptPrefill
+    calls = []
+    orig_ingest, orig_step = model.Ingest, model.Step
+    model.Ingest = lambda toks: (calls.append(("ingest", len(toks))), orig_ingest(toks))[1]
+    model.Step = lambda tok, want_logits=True: (calls.append(("step", 1)), orig_step(tok, want_logits))[1]
     text = "".join(model.RunAsync("hello world", greedy=True, max_tokens=6))
     tk = Tokenizer(md)
     ids = tk.Tokenize("hello world", addBos=True)
+    assert calls[0] == ("ingest", len(ids) - 1) and all(c == ("step", 1) for c in calls[1:])
     ref = orc.OracleLlama(odesc(dims, 128), w)
     lg = None
     for t in ids:
         lg = ref.step(t)
+    first_logits = lg
     want = []
     for _ in range(6):
         t = orc.argmax(lg)
@@ -387,6 +396,29 @@ def test_gguf_file_to_generation_end_to_end(mgr, tmp_path):
     # every prompt token and every generated token that was fed back advanced the position: the 6-token cap stops
     # before the 6th token is fed; an EOS stops after the (len(want)+1)-th sample without feeding it
     assert model.Pos == len(ids) + (5 if len(want) == 6 else len(want))
+    # the first sampled step's logits behind the MFMA-prefilled cache, against the oracle's token-by-token fp32 path: the stated
+    # fp16 tolerance of the prefill (5e-2 * max(1, max|logit|)); then the switch: promptPrefill = False is the M = 1 path bit for bit
+    model.Reset()
+    model.Ingest(ids[:-1])
+    lg_pf, _ = orig_step(ids[-1])
+    assert np.abs(lg_pf - first_logits).max() <= 5e-2 * max(1.0, float(np.abs(first_logits).max()))
+    model.Reset()
+    for t in ids[:-1]:
+        orig_step(t, False)
+    lg_tok, _ = orig_step(ids[-1])
+    assert np.abs(lg_tok - first_logits).max() <= logit_tol(first_logits)
+    model.Reset()
+    model.firstInput = True
+    model.promptPrefill = False
+    calls.clear()
+    text2 = "".join(model.RunAsync("hello world", greedy=True, max_tokens=6))
+    assert text2 == text and not any(c[0] == "ingest" for c in calls)
+    # the KV-capacity error is preserved on the prompt path: refused before anything runs
+    from nfai_amd._lib import KVCacheFull
+    model.SetPos(128 - 2)
+    with pytest.raises(KVCacheFull):
+        model.Ingest(ids[:-1])
+    assert model.Pos == 128 - 2
     model.Dispose()
 
 
