@@ -140,7 +140,7 @@ int main(void)
             if (fabsf(lg[v] - lr[v]) > maxd) maxd = fabsf(lg[v] - lr[v]);
         }
         if (maxd / maxabs > worst) worst = maxd / maxabs;
-        if (maxd > 2e-3f * maxabs || am != orc_argmax(lr, V)) bad++;   /* tests/test_gpu_model.py: logit_tol */
+        if (maxd > 5e-4f * maxabs || am != orc_argmax(lr, V)) bad++;   /* tests/test_gpu_model.py: logit_tol */
         if (i >= n_prompt) tokens[i - n_prompt] = tok;
         if (i + 1 == n_prompt) memcpy(lr_first, lr, V * 4);
     }
@@ -164,7 +164,7 @@ int main(void)
     /* RunAsync as the drop-in runs it (HipLlamaModel.RunAsync, nfai_amd.llama_model.LlamaModel.RunAsync): the prompt tokens in front
      * of the last one in ONE call on the MFMA prefill path (nfai_hip_llama_ingest: K / V rows only, fp16 operands), the last prompt
      * token through the sampled step, then the device-side greedy loop.  Stated fp16 tolerance on the first sampled step's logits
-     * (5e-2 * max(1, max|logit|), tests/test_gpu_model.py::test_prefill_mfma_matches_token_by_token), identical greedy tokens. */
+     * (2e-2 * max(1, max|logit|), tests/test_gpu_model.py::test_prefill_mfma_matches_token_by_token), identical greedy tokens. */
     CHECK(nfai_hip_llama_reset(model));
     CHECK(nfai_hip_llama_ingest(model, prompt, n_prompt - 1));
     CHECK(nfai_hip_llama_pos(model, &pos));
@@ -177,8 +177,8 @@ int main(void)
             if (fabsf(lg[v] - lr_first[v]) > maxd) maxd = fabsf(lg[v] - lr_first[v]);
         }
         printf("prompt through nfai_hip_llama_ingest (MFMA prefill, 4 + 3 tokens): first sampled step max|dlogit| = %.3g (tolerance %.3g)\n",
-               maxd, 5e-2f * maxabs);
-        if (maxd > 5e-2f * maxabs || am != tokens[0]) { fprintf(stderr, "ingest path: first sampled token %u vs %u\n", am, tokens[0]); return 1; }
+               maxd, 2e-2f * maxabs);
+        if (maxd > 2e-2f * maxabs || am != tokens[0]) { fprintf(stderr, "ingest path: first sampled token %u vs %u\n", am, tokens[0]); return 1; }
     }
     CHECK(nfai_hip_llama_decode_greedy(model, am, n_gen - 1, dev_tokens));
     for (uint32_t k = 0; k + 1 < n_gen; k++)

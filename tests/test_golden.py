@@ -69,14 +69,14 @@ def test_hip_path_against_model_fixtures(name, dims, mode):
     for i, t in enumerate(prompt):
         lg, am = m.Step(t)
         want = g["logits"][i]
-        assert np.abs(lg - want).max() <= 2e-3 * max(1.0, float(np.abs(want).max()))
+        assert np.abs(lg - want).max() <= 5e-4 * max(1.0, float(np.abs(want).max()))
     got = []
     tok = int(np.argmax(lg))
     for j in range(len(g["greedy"])):
         got.append(tok)
         lg, tok = m.Step(tok)
         want = g["logits"][len(prompt) + j]
-        assert np.abs(lg - want).max() <= 2e-3 * max(1.0, float(np.abs(want).max()))
+        assert np.abs(lg - want).max() <= 5e-4 * max(1.0, float(np.abs(want).max()))
     assert got == [int(t) for t in g["greedy"]]  # identical greedy tokens
     np.testing.assert_allclose(m.Read(0, dims.E), g["hidden_last"], rtol=0, atol=1e-3)
     np.testing.assert_allclose(m.ReadKV(0, False, len(prompt) + len(got) - 1), g["k_last_l0"], rtol=0, atol=1e-3)

@@ -156,8 +156,8 @@ def test_qkv_rope_kquant_mixed_v(mgr, vq):
         lu, _ = mu.Step(int(t))
         want = ref.step(int(t))
         scale = max(1.0, float(np.abs(want).max()))
-        assert np.abs(lg - want).max() <= 2e-3 * scale, (i, np.abs(lg - want).max())
-        assert np.abs(lu - want).max() <= 2e-3 * scale
+        assert np.abs(lg - want).max() <= 5e-4 * scale, (i, np.abs(lg - want).max())
+        assert np.abs(lu - want).max() <= 5e-4 * scale
         assert am == orc.argmax(want)
     total, _ = m.BytesPerToken(0)
     assert total < sum(a.nbytes for a in w.values() if a.ndim == 2) * 0.45  # 4.5-6.6 bits instead of 16
@@ -170,7 +170,7 @@ def test_prefill_mfma_kquant(mgr, n, chunk):
     """Q4_K_M-style model (Q4_K blocks, attn_v / ffn_down / embeddings in Q6_K) through the batched MFMA prefill: each
     block's matrices are widened to fp16 scratch and go through the fp16 GEMMs.  Oracle = token-by-token fp32 on the
     dequantised weights; stated fp16 tolerance as for the fp16 prefill (tests/test_gpu_model.py): logits
-    max|d| <= 5e-2 * max(1, max|logit|), same argmax, decode continues from the prefilled cache."""
+    max|d| <= 2e-2 * max(1, max|logit|), same argmax, decode continues from the prefilled cache."""
     from nfai_amd.llama_model import LlamaModel, QuantTensor
     dims = synth.TINY_D128
     w = synth.make_weights(dims, seed=67, std=0.05)
@@ -193,7 +193,7 @@ def test_prefill_mfma_kquant(mgr, n, chunk):
         want = ref.step(int(t))
     got = m.Prefill(toks)
     assert m.Pos == n
-    tol5 = 5e-2 * max(1.0, float(np.abs(want).max()))
+    tol5 = 2e-2 * max(1.0, float(np.abs(want).max()))
     assert np.abs(got - want).max() <= tol5, np.abs(got - want).max()
     assert int(np.argmax(got)) == orc.argmax(want)
     np.testing.assert_allclose(m.ReadKV(dims.L - 1, False, n - 1), ref.kcache(dims.L - 1)[n - 1], rtol=0, atol=2e-2)

@@ -2,7 +2,7 @@
 chain against the CPU oracle, on synthetic tiny-Llama models (the oracle finishes in seconds) and on
 one full-width block of each BASELINE model.
 
-Stated tolerances (fp32 activations, fp16 weights, fp32 KV): logits max|d| <= 2e-3 * max(1, max|logit|)
+Stated tolerances (fp32 activations, fp16 weights, fp32 KV): logits max|d| <= 5e-4 * max(1, max|logit|) (tightened in round 4: 4e-5 observed at full size)
 end to end and identical greedy tokens; with an fp16 KV cache 2e-2 (the "stated fp16 tolerance").
 """
 import numpy as np
@@ -26,7 +26,7 @@ def odesc(d, C, nfreq=None):
     return orc.LlamaDesc(E=d.E, L=d.L, H=d.H, Hkv=d.Hkv, D=d.D, F=d.F, V=d.V, C=C, rope_n_freqs=nfreq)
 
 
-def logit_tol(want, scale=2e-3):
+def logit_tol(want, scale=5e-4):
     return scale * max(1.0, float(np.abs(want).max()))
 
 
@@ -276,7 +276,7 @@ def test_attention_handoff_failure_falls_back_to_the_ticket_form(mgr, dims, capf
     for t in toks[:40]:                                  # 40 positions: two slices per kv head from here on
         lg, _ = m.Step(int(t))
         lr = ref.step(int(t))
-    tol = 2e-3 * max(1.0, float(np.abs(lr).max()))
+    tol = 5e-4 * max(1.0, float(np.abs(lr).max()))
     assert np.abs(lg - lr).max() <= tol
     lib = _lib.load()
     lib.nfai_hip_debug_attn_withhold.argtypes = [_lib.H, C.c_uint32]
@@ -397,11 +397,11 @@ def test_gguf_file_to_generation_end_to_end(mgr, tmp_path):
     # before the 6th token is fed; an EOS stops after the (len(want)+1)-th sample without feeding it
     assert model.Pos == len(ids) + (5 if len(want) == 6 else len(want))
     # the first sampled step's logits behind the MFMA-prefilled cache, against the oracle's token-by-token fp32 path: the stated
-    # fp16 tolerance of the prefill (5e-2 * max(1, max|logit|)); then the switch: promptPrefill = False is the M = 1 path bit for bit
+    # fp16 tolerance of the prefill (2e-2 * max(1, max|logit|)); then the switch: promptPrefill = False is the M = 1 path bit for bit
     model.Reset()
     model.Ingest(ids[:-1])
     lg_pf, _ = orig_step(ids[-1])
-    assert np.abs(lg_pf - first_logits).max() <= 5e-2 * max(1.0, float(np.abs(first_logits).max()))
+    assert np.abs(lg_pf - first_logits).max() <= 2e-2 * max(1.0, float(np.abs(first_logits).max()))
     model.Reset()
     for t in ids[:-1]:
         orig_step(t, False)
@@ -427,7 +427,7 @@ def test_gguf_file_to_generation_end_to_end(mgr, tmp_path):
 def test_prefill_mfma_matches_token_by_token(mgr, dims, n, chunk):
     """Batched MFMA prefill (fp16 operands, fp32 accumulate) against the oracle's token-by-token fp32
     path (the reference feeds the prompt one token at a time, LlamaModel.cs:103-126).  Stated fp16
-    tolerance: logits max|d| <= 5e-2 * max(1, max|logit|), same argmax; then decode continues from the
+    tolerance: logits max|d| <= 2e-2 * max(1, max|logit|) (round 4: was 5e-2), same argmax; then decode continues from the
     prefilled KV cache within the same tolerance."""
     from nfai_amd.llama_model import LlamaModel
     w = synth.make_weights(dims, seed=71, std=0.05)
@@ -439,7 +439,7 @@ def test_prefill_mfma_matches_token_by_token(mgr, dims, n, chunk):
         want = ref.step(int(t))
     got = m.Prefill(toks)
     assert m.Pos == n
-    tol = 5e-2 * max(1.0, float(np.abs(want).max()))
+    tol = 2e-2 * max(1.0, float(np.abs(want).max()))
     assert np.abs(got - want).max() <= tol, np.abs(got - want).max()
     assert int(np.argmax(got)) == orc.argmax(want)
     # K/V rows written by the prefill
@@ -463,7 +463,7 @@ def test_prefill_full_width_block(mgr, dims, chunk):
     oracle stays fast), T = 512 prompt tokens through the MFMA prefill — here gemm_pick takes the 128 x 128 direct-to-LDS
     kernels with the SiLU*up / fp16 epilogues and the causal tile skipping that carry the headline prefill number — against the
     oracle's token-by-token fp32 path (LlamaModel.cs:103-126).  chunk = 256: the second chunk runs with pos0 = 256.
-    Stated fp16 tolerance 5e-2 * max(1, max|logit|), same argmax, K/V rows 2e-2, then 8 decode tokens from the prefilled cache."""
+    Stated fp16 tolerance 2e-2 * max(1, max|logit|) (about 1e-1 absolute at these widths; round 4: was 5e-2), same argmax, K/V rows 2e-2, then 8 decode tokens from the prefilled cache."""
     from dataclasses import replace
     from nfai_amd.llama_model import LlamaModel
     d1 = replace(dims, L=1, V=4096, name=dims.name + "-1blk")
@@ -477,7 +477,7 @@ def test_prefill_full_width_block(mgr, dims, chunk):
     want = ref.step(int(toks[-1]))
     got = m.Prefill(toks)
     assert m.Pos == n
-    tol = 5e-2 * max(1.0, float(np.abs(want).max()))
+    tol = 2e-2 * max(1.0, float(np.abs(want).max()))
     assert np.abs(got - want).max() <= tol, np.abs(got - want).max()
     assert int(np.argmax(got)) == orc.argmax(want)
     for pos in (0, 255, 256, n - 1):
@@ -610,30 +610,100 @@ def test_engine_pipeline_stages_and_fallback(mgr):
 @pytest.mark.parametrize("quant", ["f16", "q4_k_m"])
 def test_full_size_parity_through_bench(quant):
     """The whole Llama-3.2-3B (BASELINE config 3: 28 blocks, vocabulary 128256, 6.4 GB of fp16 weights) at full size: `bench.py`
-    runs the oracle on the same weights (its `cpu_baseline` leg, here 4 tokens) and compares the first token's full logit vector
+    runs the oracle on the same weights (its `cpu_baseline` leg, here 6 tokens) and compares EVERY position's full logit vector
     with the GPU's, and compares the 512-token MFMA prefill with the token-by-token decode path.  The tolerances are the
     end-to-end ones of this file; the line must also carry the contract's roofline fields.  Also as Q4_K_M (BASELINE config 4:
-    Q4_K / Q6_K blocks; the oracle multiplies the dequantised weights)."""
+    Q4_K / Q6_K blocks; the oracle multiplies the dequantised weights).  The fp16 run is the driver's default command shape, so it
+    also appends `configs[]` — BASELINE configs 4, 2 (the whole 16-block Llama-3.2-1B) and config 5's per-GPU share (four 8B blocks
+    + the untied Q6_K lm_head), each in a child process with its own oracle comparison at full width and depth."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "16", "--warmup", "2", "--cpu-tokens", "4", "--quant", quant],
-                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "16", "--warmup", "2", "--cpu-tokens", "6", "--quant", quant],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["max_abs_logit_diff_vs_gpu_token0"] <= 2e-3   # logits are O(1) here
-    # positions 0..3 through all 28 blocks (multi-position attention at full size), greedy tokens identical at every step
-    assert len(cb["max_abs_logit_diff_vs_gpu_by_position"]) == 4 and max(cb["max_abs_logit_diff_vs_gpu_by_position"]) <= 2e-3
+    tol = 5e-4 * max(1.0, cb["max_abs_logit"])             # observed 4e-5 at 3B fp16 (logits are O(1) here), 2.3e-5 as Q4_K_M
+    assert cb["kind"] == "port" and cb["max_abs_logit_diff_vs_gpu_token0"] <= tol
+    # positions 0..5 through all 28 blocks (multi-position attention at full size), greedy tokens identical at every step
+    assert cb["positions_compared"] == 6 and len(cb["max_abs_logit_diff_vs_gpu_by_position"]) == 6 and cb["max_abs_logit_diff_vs_gpu"] <= tol
     assert all(cb["greedy_tokens_equal_by_position"]) and cb["value_1core"] > 0
     chk = d["prefill"]["check"]
     assert chk["same_argmax"] and chk["max_abs_logit_diff"] <= chk["tolerance"]
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and 0.3 < rf["frac"] < 1.0   # (`traffic` is a committed offline PMC figure, labelled so: nothing to assert on)
+    assert abs(rf["frac_of_measured_ceiling"] * rf["measured_ceiling"] - rf["frac"] * rf["peak"]) < 1e-6 * rf["achieved"]
+    classes = {k["class"]: k for k in rf["kernels"]}
+    assert {"qkv", "gateup", "down", "lmhead"} <= set(classes) and all(0.02 < k["frac"] < 1.0 for k in rf["kernels"]), rf["kernels"]
+    assert sum(k["us_per_launch"] * k["launches_per_token"] for k in rf["kernels"]) <= 1.05e3 * d["ms_per_step"]   # the kernels fit the token
     assert d["n_gpus"] == 1 and d["steps"] == 16 and d["value"] > 100
+    sp = d["sampling_path"]
+    assert sp["sampling_path_tokens_per_s"] > 50 and sp["blocking_greedy_tokens_per_s"] > 50
+    assert d["short_context"]["tokens_per_s"] >= 0.98 * d["value"]
+    if quant != "f16":
+        assert "configs" not in d
+        return
+    cfgs = d["configs"]
+    assert len(cfgs) == 3 and not any("error" in c for c in cfgs), [c.get("error") for c in cfgs]
+    for c, needle, floor in zip(cfgs, ("llama-3.2-3b Q4_K_M", "llama-3.2-1b fp16", "llama-3.1-8b Q4_K_M"), (500, 700, 500)):
+        assert needle in c["workload"] and c["value"] > floor and c["steps"] == 64, c["workload"]
+        assert 0.05 < c["token_hbm_frac_of_peak"] < 1.0 and 0.05 < c["roofline"]["frac"] < 1.0
+        assert abs(c["bytes_per_token"] / (c["ms_per_step"] * 1e-3) / 1e9 - c["token_hbm_gbps"]) < 1e-6 * c["token_hbm_gbps"]
+        pv = c["parity_vs_oracle"]
+        assert pv["positions_compared"] >= 4 and all(pv["greedy_tokens_equal_by_position"])
+        assert pv["max_abs_logit_diff"] <= 5e-4 * max(1.0, pv["max_abs_logit"]), pv
+        assert c["prefill"]["check"]["same_argmax"]
+    assert "blocks [28,32) of 32" in cfgs[2]["workload"]
+
+
+def test_timed_region_full_depth_against_the_oracle():
+    """the benchmark's own timed region against the oracle at full depth — the whole Llama-3.2-3B (28 blocks, fp16,
+    V = 128256), a 512-token prompt through the MFMA prefill, then 8 greedy tokens on the decode path (positions 512..519), against
+    `OracleLlama` fed the same 520 tokens one by one in fp32 (the reference's loop, LlamaModel.cs:103-126; ~60 s on 16 host
+    threads).  The prefill rounds its GEMM operands to fp16, so the bar is the stated fp16 tolerance on the logits
+    (2e-2 * max(1, max|logit|), about 1e-1 absolute here) with identical greedy tokens at every step; the oracle skips the lm_head for the prompt."""
+    import torch
+    import bench as B
+    from nfai_amd import _lib
+    from nfai_amd.hip import HipBufferManager
+    from nfai_amd.llama_model import LlamaModel
+    dims = synth.LLAMA_32_3B
+    torch.cuda.set_device(0)
+    weights = B.gen_weights_hbm(torch, dims, (0, dims.L), True, True, quant="f16")
+    mgr = HipBufferManager(0)
+    T, G = 512, 8
+    C = T + G + 1
+    m = LlamaModel(mgr, synth.make_metadata(dims), B.as_model_tensors(_lib, weights), C, max_batch=T,
+                   dims=dict(E=dims.E, L=dims.L, H=dims.H, Hkv=dims.Hkv, D=dims.D, F=dims.F, V=dims.V, eps=1e-5, rope_dims=dims.D, rope_base=500000.0))
+    prompt = synth.make_tokens(dims, T, seed=99)
+    prompt[0] = 128000 % dims.V
+    got = [m.Prefill(prompt)]
+    toks = [int(np.argmax(got[0]))]
+    for _ in range(G):
+        lg, am = m.Step(toks[-1])
+        got.append(lg)
+        toks.append(am)
+    assert m.Pos == T + G
+    m.Dispose()
+    ref = orc.OracleLlama(odesc(dims, C), B.host_weights(weights))
+    del weights
+    for t in prompt[:-1]:
+        ref.step(int(t), want_logits=False)
+    want = ref.step(int(prompt[-1]))
+    worst = 0.0
+    for i in range(G + 1):
+        err, scale = float(np.abs(got[i] - want).max()), max(1.0, float(np.abs(want).max()))
+        worst = max(worst, err / scale)
+        assert err <= 2e-2 * scale, (i, err, scale)
+        assert orc.argmax(want) == toks[i], (i, orc.argmax(want), toks[i])
+        if i < G:
+            want = ref.step(toks[i])
+    print(f"full-depth timed region: worst max|dlogit| / max(1, max|logit|) over {G + 1} positions = {worst:.3g}")
+    mgr.Dispose()
 
 
 @pytest.mark.parametrize("dims", [synth.LLAMA_32_3B, synth.LLAMA_32_1B], ids=lambda d: d.name)
