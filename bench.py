@@ -53,6 +53,8 @@ def parse():
                                                         "the per-GPU share of a layer pipeline (BASELINE config 5); tensor types follow the global block index")
     ap.add_argument("--configs", default="auto", help="auto: the default N=1 run appends BASELINE configs 4 (3B Q4_K_M), 2 (1B fp16) and 5's per-GPU share (8B Q4_K_M, "
                                                       "4 blocks + lm_head) as `configs[]`, each measured in a fresh child process; none: only the headline workload")
+    ap.add_argument("--pp-configs", default="auto", help="N > 1: auto = BASELINE config 5 (Llama-3.1-8B Q4_K_M over the same N stages) follows the headline "
+                                                         "entry as configs[0]; none = only the headline")
     ap.add_argument("--child", action="store_true", help="(internal) one `configs[]` entry: compact object, bounded CPU work")
     ap.add_argument("--sample-tokens", type=int, default=64, help="tokens of the sampling-path (decode_topk + host nucleus) and blocking-greedy timings (0 = skip)")
     return ap.parse_args()

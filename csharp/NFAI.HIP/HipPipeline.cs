@@ -46,6 +46,14 @@ public sealed unsafe class HipPipeline : IDisposable
         Native.Check(Native.nfai_hip_pp_info(handle, &n, &r, &d, bus));
         return (n, r, d, System.Runtime.InteropServices.Marshal.PtrToStringUTF8((nint)bus) ?? "");
     }
+    /// <summary>Throws when RCCL holds an asynchronous error for this communicator (a dead peer, a broken link): poll it once per
+    /// batch of ticks.</summary>
+    public void Check() => Native.Check(Native.nfai_hip_pp_check(handle));
+    /// <summary>Bounded synchronisation of the stage stream: returns when it is idle, throws (naming the rank) on an asynchronous
+    /// RCCL error or when the deadline passes.</summary>
+    public void Wait(TimeSpan deadline) => Native.Check(Native.nfai_hip_pp_wait(handle, (uint)Math.Min(deadline.TotalMilliseconds, uint.MaxValue)));
+    /// <summary>ncclCommAbort: releases operations that can no longer complete so that the process can leave.</summary>
+    public void Abort() => Native.Check(Native.nfai_hip_pp_abort(handle));
     public void BroadcastToken(nint tokenDev, uint root) => Native.Check(Native.nfai_hip_pp_bcast_token(handle, (void*)tokenDev, root));
 
     public void Dispose()

@@ -337,6 +337,15 @@ int32_t nfai_hip_pp_exchange(nfai_pp_t pp, const nfai_pp_op *ops, uint32_t n_ops
 /* RCCL's own view of the communicator (ncclCommCount, ncclCommUserRank, ncclCommCuDevice) and the device's PCI bus id
  * (32-byte buffer): for run records.  Any output may be NULL. */
 int32_t nfai_hip_pp_info(nfai_pp_t pp, uint32_t *nranks, uint32_t *rank, int32_t *device, char *pci_bus_id32);
+/* Failure detection (the reference has none: a failed Vulkan call throws, VulkanBufferManager.cs:61-87, and nothing watches a queue).
+ * RCCL reports a dead peer or a broken link asynchronously, after the enqueue calls returned.  _check: NFAI_OK, or NFAI_ERR_HIP with
+ * RCCL's message and this rank when ncclCommGetAsyncError holds an error.  _wait: the bounded form of "synchronise the stage
+ * stream" - polls the stream and the communicator until the stream is idle (NFAI_OK), an asynchronous error shows up, or
+ * timeout_ms passes (NFAI_ERR_HIP naming the rank).  _abort: ncclCommAbort - releases operations that can no longer complete so that
+ * the process can leave; the handle stays valid for _destroy only. */
+int32_t nfai_hip_pp_check(nfai_pp_t pp);
+int32_t nfai_hip_pp_wait(nfai_pp_t pp, uint32_t timeout_ms);
+int32_t nfai_hip_pp_abort(nfai_pp_t pp);
 
 #ifdef __cplusplus
 }

@@ -124,6 +124,9 @@ SIGNATURES = {
     "nfai_hip_pp_bcast_token": [H, vp, u32],
     "nfai_hip_pp_exchange": [H, vp, u32],
     "nfai_hip_pp_info": [H, C.POINTER(u32), C.POINTER(u32), C.POINTER(i32), C.c_char_p],
+    "nfai_hip_pp_check": [H],
+    "nfai_hip_pp_wait": [H, u32],
+    "nfai_hip_pp_abort": [H],
 }
 
 _lib = None

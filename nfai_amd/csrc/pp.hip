@@ -13,7 +13,9 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
+#include <thread>
 
 #include "common.h"
 
@@ -42,6 +44,9 @@ struct Rccl {
     Result (*GroupStart)() = nullptr;
     Result (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(Result) = nullptr;
+    // optional (bound when present): the asynchronous error of a communicator and the abort that unblocks its pending operations
+    Result (*CommGetAsyncError)(Comm, Result *) = nullptr;   // rccl.h: ncclCommGetAsyncError
+    Result (*CommAbort)(Comm) = nullptr;                     // rccl.h: ncclCommAbort
     std::string why;
 };
 
@@ -75,6 +80,8 @@ Rccl *rccl()
         SYM(GroupEnd, "ncclGroupEnd")
         SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+        r.CommGetAsyncError = reinterpret_cast<decltype(r.CommGetAsyncError)>(dlsym(r.so, "ncclCommGetAsyncError"));
+        r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.so, "ncclCommAbort"));
     });
     return &r;
 }
@@ -270,3 +277,62 @@ NFAI_API int32_t nfai_hip_pp_exchange(nfai_pp_t h, const nfai_pp_op *ops, uint32
     return NFAI_OK;
 }
 
+// ---- failure detection ("RCCL async error query; bounded spins") ---------------------------------------------------
+// RCCL reports a dead peer, a broken link or a failed proxy thread ASYNCHRONOUSLY: the enqueue calls above have long returned and
+// the stage stream simply never drains.  _check asks the communicator (ncclCommGetAsyncError); _wait is the bounded form of
+// "synchronise the stage stream": it polls the stream and the communicator until the stream is idle, an asynchronous error shows
+// up, or the deadline passes; _abort (ncclCommAbort) releases operations that can no longer complete, so that the process can
+// leave.  All three name the rank in their message; the host decides what to do (bench.py: exit code 3).
+static int pp_async_error(Rccl *r, Pp *p, const char *fn)
+{
+    if (!r->CommGetAsyncError || !p->comm) return NFAI_OK;
+    Result async = 0;
+    const Result e = r->CommGetAsyncError(p->comm, &async);
+    if (e != 0) return fail(NFAI_ERR_HIP, "%s: rank %u of %u: ncclCommGetAsyncError failed: %s", fn, p->rank, p->world, r->GetErrorString(e));
+    if (async != 0 && async != 7 /* ncclInProgress */)
+        return fail(NFAI_ERR_HIP, "%s: rank %u of %u: RCCL reports an asynchronous error on the pipeline communicator: %s", fn, p->rank, p->world,
+                    r->GetErrorString(async));
+    return NFAI_OK;
+}
+
+NFAI_API int32_t nfai_hip_pp_check(nfai_pp_t h)
+{
+    PP_OR_FAIL(p, h);
+    RCCL_OR_FAIL(r);
+    return pp_async_error(r, p, __func__);
+}
+
+NFAI_API int32_t nfai_hip_pp_wait(nfai_pp_t h, uint32_t timeout_ms)
+{
+    PP_OR_FAIL(p, h);
+    RCCL_OR_FAIL(r);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spin = 0;; spin++) {
+        const hipError_t q = hipStreamQuery(p->ctx->stream);
+        if (q == hipSuccess) return pp_async_error(r, p, __func__);
+        if (q != hipErrorNotReady) return fail(NFAI_ERR_HIP, "pp_wait: rank %u of %u: the stage stream failed: %s", p->rank, p->world, hipGetErrorString(q));
+        (void)hipGetLastError();
+        if ((spin & 63) == 63) {  // the communicator every 64 polls (a query takes a lock inside RCCL)
+            const int rc = pp_async_error(r, p, __func__);
+            if (rc) return rc;
+        }
+        const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        if ((uint64_t)ms >= timeout_ms)
+            return fail(NFAI_ERR_HIP, "pp_wait: rank %u of %u: the stage stream did not drain within %u ms (a peer that never posted its half of an "
+                                      "exchange, or a stage kernel that never finished)", p->rank, p->world, timeout_ms);
+        if (spin > 2000) std::this_thread::sleep_for(std::chrono::microseconds(200));  // short phases finish inside the busy polls
+    }
+}
+
+NFAI_API int32_t nfai_hip_pp_abort(nfai_pp_t h)
+{
+    PP_OR_FAIL(p, h);
+    RCCL_OR_FAIL(r);
+    if (!r->CommAbort) return fail(NFAI_ERR_UNSUPPORTED, "pp_abort: this RCCL has no ncclCommAbort");
+    if (p->comm) {
+        const Result e = r->CommAbort(p->comm);
+        p->comm = nullptr;  // aborted communicators are gone: _destroy only frees the handle
+        if (e != 0) return fail(NFAI_ERR_HIP, "pp_abort: rank %u of %u: ncclCommAbort failed: %s", p->rank, p->world, r->GetErrorString(e));
+    }
+    return NFAI_OK;
+}

@@ -66,8 +66,8 @@ def partition_layers(n_layers: int, world: int, layer_cost: float = 1.0, head_co
     return bounds
 
 
-def schedule_ticks(stage, rank: int, world: int, n_steps: int, first_tokens):
-    """`n_steps` tokens for each of `world` in-flight sequences (slots), as a wavefront: at tick t
+def schedule_ticks(stage, rank: int, world: int, n_steps: int, first_tokens, n_slots: int | None = None):
+    """`n_steps` tokens for each of `n_slots` (default `world`: the pipeline exactly full) in-flight sequences (slots), as a wavefront: at tick t
     stage r runs job j = t - r (slot j % world, step j // world); after the compute of a tick every
     rank posts ONE batch of point-to-point operations (send my result on, receive what I need for the
     next tick).  Both ends of every link post in the same tick, so the schedule cannot deadlock even
@@ -79,13 +79,18 @@ def schedule_ticks(stage, rank: int, world: int, n_steps: int, first_tokens):
     Generator: runs this rank's compute of a tick, then yields (sends=[(buf, dst)], recvs=[(buf, src)]) for
     the exchange that follows it (empty lists when the rank has nothing to post).
 
+    n_slots < world leaves the jobs of the slots >= n_slots out (same ticks, same links): n_slots = 1 is ONE sequence travelling
+    through the stages — the single-stream latency of the pipeline, every stage idle world - 1 ticks out of world.
+
     stage API: first(slot, token_host | None) [rank 0; None = use the received token buffer],
     middle(slot), last(slot), last_from_first(slot) [world == 1]; buffers h_in(slot), h_out(slot), tok(slot)."""
     last = world - 1
     n_jobs = n_steps * world
+    n_slots = world if n_slots is None else n_slots
+    assert 1 <= n_slots <= world
     for tick in range(n_jobs + world - 1):
         j = tick - rank
-        active = 0 <= j < n_jobs
+        active = 0 <= j < n_jobs and j % world < n_slots
         sends, recvs = [], []
         if active:
             slot, step = j % world, j // world
@@ -102,7 +107,7 @@ def schedule_ticks(stage, rank: int, world: int, n_steps: int, first_tokens):
             elif step + 1 < n_steps and world > 1:
                 sends.append((stage.tok(slot), 0))
         j2 = tick + 1 - rank
-        if 0 <= j2 < n_jobs and world > 1:
+        if 0 <= j2 < n_jobs and world > 1 and j2 % world < n_slots:
             slot2, step2 = j2 % world, j2 // world
             if rank > 0:
                 recvs.append((stage.h_in(slot2), rank - 1))
@@ -111,19 +116,23 @@ def schedule_ticks(stage, rank: int, world: int, n_steps: int, first_tokens):
         yield sends, recvs
 
 
-def run_schedule(stage, comm, rank: int, world: int, n_steps: int, first_tokens):
-    """One rank's side of the schedule (one process per GPU).  comm API: exchange(sends, recvs)."""
-    for sends, recvs in schedule_ticks(stage, rank, world, n_steps, first_tokens):
+def run_schedule(stage, comm, rank: int, world: int, n_steps: int, first_tokens, n_slots: int | None = None):
+    """One rank's side of the schedule (one process per GPU).  comm API: exchange(sends, recvs); optional check() — the backend's
+    asynchronous-error query (RCCL: ncclCommGetAsyncError), polled once per batch of `world` ticks; it raises."""
+    check = getattr(comm, "check", None)
+    for tick, (sends, recvs) in enumerate(schedule_ticks(stage, rank, world, n_steps, first_tokens, n_slots)):
         if sends or recvs:
             comm.exchange(sends, recvs)
+        if check is not None and tick % world == world - 1:
+            check()
 
 
-def run_schedule_in_process(stages, n_steps: int, first_tokens, copy):
+def run_schedule_in_process(stages, n_steps: int, first_tokens, copy, n_slots: int | None = None):
     """All `world` stages of the pipeline driven by ONE process in lock step (stages that share a device, or a host with
     several GPUs in one address space): every tick each rank computes, then the posted sends are matched with the posted
     receives (same tick, same link) and carried out by `copy(dst_buf, src_buf)`."""
     world = len(stages)
-    gens = [schedule_ticks(st, r, world, n_steps, first_tokens) for r, st in enumerate(stages)]
+    gens = [schedule_ticks(st, r, world, n_steps, first_tokens, n_slots) for r, st in enumerate(stages)]
     for posted in zip(*gens):
         for r, (sends, _) in enumerate(posted):
             for buf, dst in sends:
@@ -222,6 +231,17 @@ class RcclComm:
                 call("nfai_hip_pp_recv_hidden", self.handle, C.c_void_p(t.data_ptr()), t.numel(), src)
         call("nfai_hip_pp_end", self.handle)
 
+    def check(self) -> None:
+        """Raises NfaiHipError (naming the rank) when RCCL holds an asynchronous error for the communicator."""
+        self._lib.call("nfai_hip_pp_check", self.handle)
+
+    def wait(self, timeout_s: float) -> None:
+        """Bounded synchronisation of the stage stream (nfai_hip_pp_wait): raises on an asynchronous RCCL error or at the deadline."""
+        self._lib.call("nfai_hip_pp_wait", self.handle, int(min(timeout_s * 1e3, 0xFFFFFFFF)))
+
+    def abort(self) -> None:
+        self._lib.call("nfai_hip_pp_abort", self.handle)
+
     def info(self) -> dict:
         """RCCL's own view: ncclCommCount, ncclCommUserRank, ncclCommCuDevice + the device's PCI bus id."""
         C = self._C
@@ -296,11 +316,75 @@ class HipStage:
             m.Dispose()
 
 
+class PhaseWatchdog:
+    """A deadline for EVERY phase of a pipeline run (the first exchanges that open RCCL's channels, the context fill, the timed
+    regions).  A rank that cannot finish a phase — a peer that died, a transport that cannot be set up, a stage kernel that never
+    returns — would leave every other rank waiting inside RCCL for ever: when a phase overruns, the rank prints its rank, its block
+    range, the phase and the exchange in use and leaves with exit code 3 (the launcher then ends the other ranks).  A fresh exit,
+    never a re-exec."""
+
+    def __init__(self, rank: int, describe, exit_fn=None):
+        self.rank, self.describe = rank, describe
+        self._exit = exit_fn or (lambda code: os._exit(code))
+        self._lock = threading.Lock()
+        self._deadline = None
+        self._name = ""
+        self.fired = None
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+
+    def _run(self):
+        while True:
+            time.sleep(0.05)
+            with self._lock:
+                late = self._deadline is not None and time.monotonic() > self._deadline
+                name, limit = self._name, self._limit if late else 0.0
+                if late:
+                    self._deadline = None
+            if late:
+                self.fired = name
+                print(f"[rank {self.rank}] {self.describe()}: phase '{name}' did not complete within {limit:.0f} s; giving up (exit code 3)",
+                      file=sys.stderr, flush=True)
+                self._exit(3)
+
+    def phase(self, name: str, limit_s: float):
+        wd = self
+
+        class _Phase:
+            def __enter__(self_inner):
+                with wd._lock:
+                    wd._name, wd._limit, wd._deadline = name, limit_s, time.monotonic() + limit_s
+
+            def __exit__(self_inner, *exc):
+                with wd._lock:
+                    wd._deadline = None
+                return False
+
+        return _Phase()
+
+
+def pipeline_costs(dims, quant: str) -> tuple[float, float]:
+    """(bytes one block streams per token, bytes of the lm_head) under the file type: what partition_layers balances.  Q4_K_M files
+    keep attn_v / ffn_down in Q6_K on about half of the blocks (bench.tensor_type); the average block is used."""
+    import bench as B
+    bits = {1: 16.0, B.Q4_K: 4.5, B.Q6_K: 6.5625}
+    tot = 0.0
+    for name, shape in dims.shapes().items():
+        if name.startswith("blk.") and len(shape) == 2:
+            tot += shape[0] * shape[1] * bits[B.tensor_type(name, dims, quant)] / 8
+    head = "output.weight" if not dims.tied else "token_embd.weight"
+    return tot / dims.L, dims.V * dims.E * bits[B.tensor_type(head, dims, quant)] / 8
+
+
 def run_bench_pipeline(args):
-    """bench.py for N > 1: one process per GPU (torch.distributed.run), RCCL point-to-point."""
+    """bench.py for N > 1: one process per GPU (torch.distributed.run), RCCL point-to-point.  The headline entry is the metric's
+    model (Llama-3.2-3B, --quant) over `world` stages; BASELINE config 5 (Llama-3.1-8B Q4_K_M) follows as `configs[0]` in the same
+    process group.  Each entry reports the aggregate of `world` sequences in flight AND the single-stream figure (one sequence
+    travelling through the stages: <= the 1-GPU figure, the hops only add latency — SURVEY 8e)."""
     import torch
     import torch.distributed as dist
     from . import synth
+    from ._lib import NfaiHipError
     from .hip import HipBufferManager
     import bench as B  # weight generator shared with the single-GPU bench
 
@@ -324,44 +408,42 @@ def run_bench_pipeline(args):
         dist.init_process_group("gloo")
     else:
         dist.init_process_group("cpu:gloo,cuda:nccl", device_id=torch.device("cuda", local))
-    dims = synth.BY_NAME[args.model]
-    layer_bytes = (2 * dims.H * dims.D * dims.E + 2 * dims.Hkv * dims.D * dims.E + 3 * dims.F * dims.E) * 2
-    head_bytes = dims.V * dims.E * 2
-    ranges = partition_layers(dims.L, world, layer_bytes, head_bytes)
-    lb, le = ranges[rank]
-    first, last = rank == 0, rank == world - 1
-    weights = B.gen_weights_hbm(torch, dims, (lb, le), first, last, seed=1234 + rank, quant=args.quant)
     stream = torch.cuda.Stream()
-    C = args.context + args.warmup + args.steps
+    init_limit = float(os.environ.get("NFAI_PP_INIT_TIMEOUT", "240"))
+    phase_limit = float(os.environ.get("NFAI_PP_PHASE_TIMEOUT", "300"))
+    where = {"text": "setting up"}
+    wd = PhaseWatchdog(rank, lambda: where["text"])
+
     with torch.cuda.stream(stream):
         mgr = HipBufferManager(local, stream=stream.cuda_stream)
-        stage = HipStage(torch, mgr, dims, (lb, le), weights, world, C, rank, world, kv_f16=args.kv_f16, graph=not args.no_graph)
-        if use_cabi:
-            # every rank learns whether ALL ranks got their communicator (a rank that failed must not leave the others in a
-            # collective): if not, the exchange falls back to torch.distributed's own NCCL binding and the line says so
-            comm, why = None, ""
-            try:
-                box = [RcclComm.unique_id() if rank == 0 else None]
-            except Exception as e:  # noqa: BLE001 - reported below, the run continues on the torch binding
-                box, why = [None], repr(e)
-            dist.broadcast_object_list(box, src=0)
-            if box[0] is not None:
+        with wd.phase("communicator set-up", init_limit):
+            if use_cabi:
+                # every rank learns whether ALL ranks got their communicator (a rank that failed must not leave the others in a
+                # collective): if not, the exchange falls back to torch.distributed's own NCCL binding and the line says so
+                comm, why = None, ""
                 try:
-                    comm = RcclComm(mgr, rank, world, box[0])
-                except Exception as e:  # noqa: BLE001
-                    why = repr(e)
-            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                if comm is not None:
-                    comm.close()
-                print(f"[rank {rank}] nfai_hip_pp_* communicator not available on every rank ({why or 'another rank failed'}): "
-                      "exchange through torch.distributed (nccl)", file=sys.stderr, flush=True)
-                use_cabi = False
-                comm = TorchComm(dist, group=dist.new_group(backend="nccl"))
-        else:
-            comm = TorchComm(dist, stage_through_host=rehearsal)
-        toks =[(128000 + 17 * s) % dims.V for s in range(world)]
+                    box = [RcclComm.unique_id() if rank == 0 else None]
+                except Exception as e:  # noqa: BLE001 - reported below, the run continues on the torch binding
+                    box, why = [None], repr(e)
+                dist.broadcast_object_list(box, src=0)
+                if box[0] is not None:
+                    try:
+                        comm = RcclComm(mgr, rank, world, box[0])
+                    except Exception as e:  # noqa: BLE001
+                        why = repr(e)
+                ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    if comm is not None:
+                        comm.close()
+                    print(f"[rank {rank}] nfai_hip_pp_* communicator not available on every rank ({why or 'another rank failed'}): "
+                          "exchange through torch.distributed (nccl)", file=sys.stderr, flush=True)
+                    use_cabi = False
+                    comm = TorchComm(dist, group=dist.new_group(backend="nccl"))
+            else:
+                comm = TorchComm(dist, stage_through_host=rehearsal)
+        exchange_name = ("nfai_hip_pp_exchange (RCCL send/recv, one group per tick on the stage stream)" if use_cabi
+                         else ("gloo via host (one-card rehearsal)" if rehearsal else "torch.distributed nccl"))
         # RCCL's own record of the communicator, gathered over gloo: the line shows that RCCL saw `world` ranks on `world` devices
         rccl_view = None
         if use_cabi:
@@ -369,67 +451,132 @@ def run_bench_pipeline(args):
             dist.all_gather_object(views, comm.info())
             rccl_view = {"nranks": views[0]["nranks"], "ranks": sorted(views, key=lambda v: v["rank"]),
                          "distinct_devices": len({v["pci_bus_id"] for v in views})}
-        # The first exchanges open the RCCL channels (xGMI peer mappings, proxy threads).  A rank that never gets there (a peer
-        # missing, a transport that cannot be set up) would leave every other rank waiting inside RCCL for ever: a watchdog
-        # bounds the first `world` + 1 ticks and leaves the process with a message naming rank and stage (exit code 3; the
-        # launcher then ends the other ranks).  Never a re-exec.
-        first_ticks = threading.Event()
-        limit = float(os.environ.get("NFAI_PP_INIT_TIMEOUT", "240"))
 
-        def watchdog():
-            if not first_ticks.wait(limit):
-                print(f"[rank {rank}] stage blocks [{lb},{le}) of {dims.name}: the first pipeline exchanges did not complete within {limit:.0f} s "
-                      f"(exchange: {'nfai_hip_pp_* / RCCL' if use_cabi else 'torch.distributed'}); giving up", file=sys.stderr, flush=True)
-                os._exit(3)
+        def drain(limit):
+            """Bounded synchronisation of the stage stream: nfai_hip_pp_wait polls the stream AND ncclCommGetAsyncError."""
+            if hasattr(comm, "wait"):
+                comm.wait(limit)
+            else:
+                stream.synchronize()
 
-        threading.Thread(target=watchdog, daemon=True).start()
-        run_schedule(stage, comm, rank, world, world + 1, toks)
-        stream.synchronize()
-        first_ticks.set()
-        # context fill + warmup (also instantiates the stage graphs); the sequences restart from their first tokens
-        for mdl in stage.models:
-            mdl.Reset()
-        run_schedule(stage, comm, rank, world, args.context + args.warmup, toks)
-        stream.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        # the timed region continues every sequence from its last token
-        if first:
-            # the last stage did not send the final token of the fill phase: restart from fixed tokens
-            pass
-        run_schedule(stage, comm, rank, world, args.steps, toks)
-        stream.synchronize()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device="cpu", dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dist.barrier()
-    dt = float(t.item())
-    n_tok = world * args.steps
-    # bytes this rank streams per step (all its sequences), for the per-GPU achieved bandwidth
-    pos_mid = args.context + args.warmup + args.steps // 2
-    b_rank = sum(stage.models[0].BytesPerToken(pos_mid)[0] for _ in range(world))
-    gb = torch.tensor([b_rank / 1e9], device="cpu", dtype=torch.float64)
-    dist.all_reduce(gb, op=dist.ReduceOp.SUM)
+        def give_up(phase, err):
+            print(f"[rank {rank}] {where['text']}: phase '{phase}' failed: {err}; giving up (exit code 3)", file=sys.stderr, flush=True)
+            try:
+                if hasattr(comm, "abort"):
+                    comm.abort()   # releases what can no longer complete, so that the process can leave
+            except Exception:  # noqa: BLE001
+                pass
+            os._exit(3)
+
+        def measure(model_name, quant, headline):
+            dims = synth.BY_NAME[model_name]
+            layer_bytes, head_bytes = pipeline_costs(dims, quant)
+            ranges = partition_layers(dims.L, world, layer_bytes, head_bytes)
+            lb, le = ranges[rank]
+            first, last = rank == 0, rank == world - 1
+            where["text"] = f"stage blocks [{lb},{le}) of {dims.name} ({quant}; exchange: {exchange_name})"
+            weights = B.gen_weights_hbm(torch, dims, (lb, le), first, last, seed=1234 + rank, quant=quant)
+            n_single = max(args.steps, 4)
+            C = args.context + args.warmup + args.steps + n_single
+            stage = HipStage(torch, mgr, dims, (lb, le), weights, world, C, rank, world, kv_f16=args.kv_f16, graph=not args.no_graph)
+            toks = [(128000 + 17 * s) % dims.V for s in range(world)]
+            phase = "?"
+            try:
+                # The first exchanges open the RCCL channels (xGMI peer mappings, proxy threads)
+                phase = "first exchanges"
+                with wd.phase(phase, init_limit):
+                    run_schedule(stage, comm, rank, world, world + 1, toks)
+                    drain(init_limit)
+                # context fill + warmup (also instantiates the stage graphs); the sequences restart from their first tokens
+                for mdl in stage.models:
+                    mdl.Reset()
+                phase = "context fill"
+                with wd.phase(phase, phase_limit):
+                    run_schedule(stage, comm, rank, world, args.context + args.warmup, toks)
+                    drain(phase_limit)
+                    dist.barrier()
+                torch.cuda.synchronize()
+                # ---- timed region 1: `world` sequences in flight (the pipeline exactly full), `steps` tokens each
+                phase = "timed region (pipeline full)"
+                with wd.phase(phase, phase_limit):
+                    t0 = time.perf_counter()
+                    run_schedule(stage, comm, rank, world, args.steps, toks)
+                    drain(phase_limit)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                    t = torch.tensor([dt], device="cpu", dtype=torch.float64)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    dist.barrier()
+                dt = float(t.item())
+                # ---- timed region 2: ONE sequence travelling through the stages (slot 0 continues): the single-stream latency
+                phase = "timed region (single stream)"
+                with wd.phase(phase, phase_limit):
+                    run_schedule(stage, comm, rank, world, 2, toks, n_slots=1)   # the pattern's operation arrays, untimed
+                    drain(phase_limit)
+                    dist.barrier()
+                    t0 = time.perf_counter()
+                    run_schedule(stage, comm, rank, world, n_single - 2, toks, n_slots=1)
+                    drain(phase_limit)
+                    torch.cuda.synchronize()
+                    dt1 = time.perf_counter() - t0
+                    t = torch.tensor([dt1], device="cpu", dtype=torch.float64)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    dist.barrier()
+                dt1 = float(t.item())
+            except NfaiHipError as e:
+                give_up(phase, e)
+            n_tok = world * args.steps
+            # bytes this rank streams per step (all its sequences), for the per-GPU achieved bandwidth
+            pos_mid = args.context + args.warmup + args.steps // 2
+            b_rank = sum(stage.models[0].BytesPerToken(pos_mid)[0] for _ in range(world))
+            gb = torch.tensor([b_rank / 1e9], device="cpu", dtype=torch.float64)
+            dist.all_reduce(gb, op=dist.ReduceOp.SUM)
+            stage.dispose()
+            del weights
+            torch.cuda.empty_cache()
+            if rank != 0:
+                return None
+            ach = float(gb.item()) * args.steps / dt / world
+            qname = "fp16-GGUF" if quant == "f16" else "Q4_K_M-GGUF"
+            return {
+                "value": n_tok / dt, "unit": "tokens/s", "ms_per_step": 1e3 * dt / args.steps,
+                "sequences_in_flight": world,
+                "single_stream_tokens_per_s": (n_single - 2) / dt1, "single_stream_ms_per_token": 1e3 * dt1 / (n_single - 2),
+                "single_stream_note": f"ONE sequence through the {world} stages ({world} stage graphs + {world} point-to-point hops per token): at batch 1 a "
+                                      "layer pipeline cannot be faster than one GPU holding the whole model - capacity scales, latency does not (SURVEY 8e); "
+                                      f"`value` is the aggregate of {world} independent sequences in flight",
+                "config": {"workload": f"{dims.name} {qname} weights, fp32 activations + {'fp16' if args.kv_f16 else 'fp32'} KV, "
+                                       f"{world} independent batch-1 greedy sequences in flight over a {world}-stage layer pipeline, "
+                                       f"{args.steps} tokens each after a {args.context}-token context; then one sequence alone for {n_single - 2} tokens",
+                           "parallelism": f"pp{world}", "layer_ranges": ranges, "kv_capacity": C,
+                           "exchange": exchange_name, "rccl": rccl_view,
+                           "async_error_poll": "ncclCommGetAsyncError once per batch of `world` ticks (nfai_hip_pp_check) and inside every bounded stream wait "
+                                               "(nfai_hip_pp_wait)" if use_cabi else None,
+                           "phase_deadlines_s": {"first exchanges": init_limit, "every later phase": phase_limit},
+                           "multi_rank_rccl_note": None if not rehearsal else "one-card rehearsal over gloo: RCCL did not run",
+                           "command": f"python bench.py --gpus {world} --model {model_name} --quant {quant} --steps {args.steps} --warmup {args.warmup}"},
+                "roofline": {"bound": "hbm", "achieved": ach, "peak": B.HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / B.HBM_PEAK_GBPS,
+                             "frac_of_measured_ceiling": ach / B.HBM_MEASURED_CEILING_GBPS, "traffic": None,
+                             "kernel": "per-GPU average over the whole step (all kernels of the stage)"},
+            }
+
+        head = measure(args.model, args.quant, True)
+        second = None
+        if getattr(args, "pp_configs", "auto") != "none" and not (args.model == "llama-3.1-8b" and args.quant == "q4_k_m"):
+            second = measure("llama-3.1-8b", "q4_k_m", False)   # BASELINE config 5
     if rank == 0:
         out = {
             "metric": "decode tokens/sec Llama-3.2-3B batch=1; achieved HBM GB/s vs roofline",
-            "value": n_tok / dt, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": head["value"], "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{dims.name} {'fp16-GGUF' if args.quant == 'f16' else 'Q4_K_M-GGUF'} weights, fp32 activations + {'fp16' if args.kv_f16 else 'fp32'} KV, "
-                                   f"{world} independent batch-1 greedy sequences in flight over a {world}-stage layer pipeline, "
-                                   f"{args.steps} tokens each after a {args.context}-token context",
-                       "parallelism": f"pp{world}", "layer_ranges": ranges, "kv_capacity": C,
-                       "exchange": "nfai_hip_pp_exchange (RCCL send/recv, one group per tick on the stage stream)" if use_cabi else ("gloo via host (one-card rehearsal)" if rehearsal else "torch.distributed nccl"),
-                       "rccl": rccl_view,
-                       "command": f"python bench.py --gpus {world} --model {args.model} --quant {args.quant} --steps {args.steps} --warmup {args.warmup}"},
-            "roofline": {"bound": "hbm", "achieved": float(gb.item()) * args.steps / dt / world, "peak": B.HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": float(gb.item()) * args.steps / dt / world / B.HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "per-GPU average over the whole step (all kernels of the stage)"},
-            "cpu_baseline": None,
+            "sequences_in_flight": world, "single_stream_tokens_per_s": head["single_stream_tokens_per_s"],
+            "single_stream_ms_per_token": head["single_stream_ms_per_token"], "single_stream_note": head["single_stream_note"],
+            "config": head["config"], "roofline": head["roofline"], "cpu_baseline": None,
         }
+        if second is not None:
+            second["baseline_config"] = f"BASELINE config 5: Llama-3.1-8B-Instruct Q4_K_M GGUF, layers pipeline-sharded across {world}xMI355X over RCCL/xGMI"
+            out["configs"] = [second]
         print(json.dumps(out))
     if use_cabi:
         comm.close()

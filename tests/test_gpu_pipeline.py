@@ -183,6 +183,21 @@ def test_rccl_exchange_one_rank(env):
         _lib.call("nfai_hip_pp_bcast_token", comm.handle, C.c_void_p(tb.data_ptr()), 0)
         stream.synchronize()
         assert int(tb.item()) == 123456
+        # failure detection: no asynchronous error on a healthy communicator; the bounded wait returns at once on an idle stream,
+        # covers enqueued work, and reports a stream that does not drain by its deadline (a long-running kernel stands in for a
+        # peer that never posts its half of an exchange), naming the rank
+        comm.check()
+        comm.wait(5.0)
+        comm.exchange([(a, 0), (ta, 0)], [(b, 0), (tb, 0)])
+        comm.wait(30.0)
+        assert torch.equal(a, b)
+        big = torch.empty(1 << 28, device="cuda", dtype=torch.float32)
+        for _ in range(40):
+            big.mul_(1.0001)                                            # ~40 x 2 GB of traffic: tens of milliseconds on the stage stream
+        with pytest.raises(L.NfaiHipError, match="rank 0 of 1: the stage stream did not drain within 1 ms"):
+            comm.wait(0.001)
+        comm.wait(60.0)
+        del big
         comm.close()
 
 
@@ -210,10 +225,18 @@ def test_bench_two_rank_rehearsal_on_one_card():
     env = dict(os.environ, NFAI_PP_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--model", "llama-3.2-1b"],
-                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--model", "llama-3.2-1b",
+                        "--context", "96"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["parallelism"] == "pp2" and len(d["config"]["layer_ranges"]) == 2
+    # the single-stream figure beside the aggregate ("`world` sequences in flight" stated), per-phase deadlines,
+    # and BASELINE config 5 (Llama-3.1-8B Q4_K_M over the same stages) as a second entry of the same line
+    assert d["sequences_in_flight"] == 2 and 0 < d["single_stream_tokens_per_s"] and "2 independent" in d["config"]["workload"]
+    assert d["single_stream_tokens_per_s"] <= 1.05 * d["value"]          # one stream is never faster than the full pipeline's aggregate
+    assert d["config"]["phase_deadlines_s"]["first exchanges"] > 0 and "RCCL did not run" in d["config"]["multi_rank_rccl_note"]
+    c5 = d["configs"][0]
+    assert "config 5" in c5["baseline_config"] and "llama-3.1-8b Q4_K_M" in c5["config"]["workload"] and c5["value"] > 0
+    assert c5["single_stream_tokens_per_s"] > 0 and len(c5["config"]["layer_ranges"]) == 2 and c5["config"]["layer_ranges"][-1][1] == 32

@@ -76,7 +76,21 @@ class _OracleStage:
         self._tok[slot][0] = t
 
 
-def _worker(rank, world, port, n_steps, q):
+class _CountingComm:
+    """TorchComm + the optional `check` hook run_schedule polls once per batch of `world` ticks (RCCL: ncclCommGetAsyncError)."""
+
+    def __init__(self, inner):
+        self.inner, self.checks, self.exchanges = inner, 0, 0
+
+    def exchange(self, sends, recvs):
+        self.exchanges += 1
+        self.inner.exchange(sends, recvs)
+
+    def check(self):
+        self.checks += 1
+
+
+def _worker(rank, world, port, n_steps, q, n_single=0):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -86,9 +100,22 @@ def _worker(rank, world, port, n_steps, q):
     dims = synth.TINY_D128
     w = synth.make_weights(dims, seed=41, std=0.05)
     ranges = partition_layers(dims.L, world)
-    stage = _OracleStage(torch, dims, w, ranges[rank], world, n_steps + 1)
+    stage = _OracleStage(torch, dims, w, ranges[rank], world, n_steps + n_single + 1)
     first = [3 + 11 * s for s in range(world)]
-    run_schedule(stage, TorchComm(dist), rank, world, n_steps, first)
+    comm = _CountingComm(TorchComm(dist))
+    run_schedule(stage, comm, rank, world, n_steps, first)
+    n_ticks = n_steps * world + world - 1
+    assert comm.checks == n_ticks // world, (comm.checks, n_ticks)
+    if n_single:
+        # bench.py's second timed region: ONE sequence (slot 0) continues alone through the stages; its first token is handed
+        # over by the host again, as run_bench_pipeline does
+        dist.barrier()
+        nxt = [stage.tokens[0][-1]] if rank == world - 1 else [None]
+        dist.broadcast_object_list(nxt, src=world - 1)
+        before = comm.exchanges
+        run_schedule(stage, comm, rank, world, n_single, [nxt[0]] + first[1:], n_slots=1)
+        # one hop per tick and link: a middle stage posts a receive and a send per token, the ends one fewer at the edges
+        assert comm.exchanges - before <= 2 * n_single + 1
     dist.barrier()
     if rank == world - 1:
         q.put(stage.tokens)
@@ -101,15 +128,17 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_pipeline_schedule_gloo(world):
+@pytest.mark.parametrize("world,n_single", [(2, 0), (3, 0), (2, 4), (3, 3)])
+def test_pipeline_schedule_gloo(world, n_single):
+    """n_single > 0: after the pipeline-full phase slot 0 continues ALONE for n_single tokens (schedule_ticks(..., n_slots=1):
+    bench.py's single-stream region) — its tokens must continue the single-process greedy decode exactly."""
     import torch.multiprocessing as mp
     import oracle as orc
     n_steps = 6
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_steps, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_steps, q, n_single)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=180)
@@ -118,14 +147,37 @@ def test_pipeline_schedule_gloo(world):
         assert p.exitcode == 0
     dims = synth.TINY_D128
     w = synth.make_weights(dims, seed=41, std=0.05)
-    desc = orc.LlamaDesc(E=dims.E, L=dims.L, H=dims.H, Hkv=dims.Hkv, D=dims.D, F=dims.F, V=dims.V, C=n_steps + 1)
+    desc = orc.LlamaDesc(E=dims.E, L=dims.L, H=dims.H, Hkv=dims.Hkv, D=dims.D, F=dims.F, V=dims.V, C=n_steps + n_single + 1)
     for s in range(world):
         ref = orc.OracleLlama(desc, w)
         tok, want = 3 + 11 * s, []
-        for _ in range(n_steps):
+        for _ in range(n_steps + (n_single if s == 0 else 0)):
             tok = orc.argmax(ref.step(tok))
             want.append(tok)
         assert got[s] == want, (s, got[s], want)
+
+
+def test_phase_watchdog_and_costs():
+    """The per-phase deadline of a pipeline run: a phase that finishes in time disarms it; one that overruns
+    makes the rank print rank / stage / phase and leave through the exit hook (os._exit(3) in bench.py; a recorder here).
+    pipeline_costs: the bytes partition_layers balances follow the file type."""
+    import time
+    from nfai_amd.pipeline import PhaseWatchdog, pipeline_costs
+    codes = []
+    wd = PhaseWatchdog(5, lambda: "stage blocks [4,8) of test-model", exit_fn=codes.append)
+    with wd.phase("quick", 0.5):
+        time.sleep(0.05)
+    time.sleep(0.7)
+    assert codes == [] and wd.fired is None           # disarmed on exit
+    with wd.phase("stuck exchange", 0.15):
+        time.sleep(0.6)
+    assert codes == [3] and wd.fired == "stuck exchange"
+    lb, hb = pipeline_costs(synth.LLAMA_31_8B, "f16")
+    assert lb == (2 * 4096 * 4096 + 2 * 1024 * 4096 + 3 * 14336 * 4096) * 2 and hb == 128256 * 4096 * 2
+    lq, hq = pipeline_costs(synth.LLAMA_31_8B, "q4_k_m")
+    assert 0.28 * lb < lq < 0.33 * lb and abs(hq - 128256 * 4096 * 6.5625 / 8) < 1      # Q4_K with Q6_K v / down on half the blocks; Q6_K head
+    r = partition_layers(32, 8, lq, hq)
+    assert r[-1][1] - r[-1][0] < r[0][1] - r[0][0]    # the last stage also streams the lm_head: fewer blocks
 
 
 # ---- properties of the host logic (hypothesis): any world size, any model depth ------------------------------------------------
@@ -179,6 +231,31 @@ class _TraceStage:
 
     def last_from_first(self, slot):
         self.calls.append(("last_from_first", slot))
+
+
+@settings(max_examples=40, deadline=None)
+@given(world=st.integers(2, 8), n_steps=st.integers(1, 6), data=st.data())
+def test_schedule_ticks_fewer_slots_properties(world, n_steps, data):
+    """n_slots < world (n_slots = 1: the single-stream region of bench.py): same ticks and links, every posted send still has its
+    receive in the same tick, only the jobs of slots < n_slots run, each exactly n_steps times per stage and in order."""
+    from nfai_amd.pipeline import schedule_ticks
+    n_slots = data.draw(st.integers(1, world))
+    stages = [_TraceStage() for _ in range(world)]
+    firsts = [100 + s for s in range(world)]
+    gens = [schedule_ticks(stages[r], r, world, n_steps, firsts, n_slots) for r in range(world)]
+    n_sends = 0
+    for posted in zip(*gens):
+        for r, (sends, recvs) in enumerate(posted):
+            for buf, dst in sends:
+                match = [b for b, src in posted[dst][1] if src == r]
+                assert len(match) == 1 and match[0][1] == buf[1] < n_slots
+                n_sends += 1
+        assert sum(len(s_) for s_, _ in posted) == sum(len(r_) for _, r_ in posted)
+    assert n_sends == n_slots * (n_steps * (world - 1) + (n_steps - 1))   # hidden hops + token returns
+    for r, stg in enumerate(stages):
+        kind = "first" if r == 0 else ("last" if r == world - 1 else "middle")
+        jobs = [c for c in stg.calls if c[0] == kind]
+        assert len(jobs) == n_steps * n_slots and {c[1] for c in jobs} == set(range(n_slots))
 
 
 @settings(max_examples=60, deadline=None)
