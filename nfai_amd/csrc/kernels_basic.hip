@@ -284,19 +284,28 @@ hipError_t launch_argmax(const float *x, uint32_t n, uint32_t *out_idx, void *pa
 // ---------------------------------------------------------------------------------------------
 // Candidates for SamplingUtils.TopP (SamplingUtils.cs:5-33), the sampler LlamaModel.RunAsync actually calls (LlamaModel.cs:130,
 // 165).  The reference divides all V logits by the temperature, takes a softmax over V, sorts V (index, probability) pairs and
-// keeps the first topK = 40 — on the host, after reading 513 KB of logits back.  Here ONE launch leaves on the device what the
-// rest of TopP needs: the k largest logits with their indices (ties: lower index first, as the stable OrderByDescending :9-12
-// orders equal probabilities), max_i(l_i / T) and sum_i exp(l_i / T - max): 8k + 8 bytes go to the host, which forms the k
+// keeps the first topK = 40 — on the host, after reading 513 KB of logits back.  Here two short launches leave on the device what
+// the rest of TopP needs: the k largest logits with their indices (ties: lower index first, as the stable OrderByDescending :9-12
+// orders equal probabilities), M = max_i(l_i / T) and S = sum_i exp(l_i / T - M): 8k + 8 bytes go to the host, which forms the k
 // probabilities, cuts the nucleus and draws (llama.hip: nfai_hip_llama_decode_topk).
-//   level 1: every wave owns a contiguous range of the logits (<= TOPK_NT per lane, in registers) and extracts its k best by k
-//            rounds of [lane-local best -> wave-wide best (DPP inside rows of 16, v_readlane across rows) -> owner retires it];
-//            list, (max, sum of exp) of the range -> workspace (write-through), one ticket per block;
-//   level 2: the block whose ticket is last merges the sorted lists: a thread keeps the heads of its lists, k rounds of
-//            [thread-local best head -> block-wide best -> owner advances]; (max, sum) pairs are combined in fixed order.
-// NaN-free, finite logits assumed (as k_argmax).
+//   k_topk_heads : every wave owns a contiguous range of the logits (<= TOPK_NT per lane) and stores the range's best (value,
+//                  index) — its "head".
+//   k_topk_select: (a) every workgroup ranks the nw heads (LDS, counting) and takes tau = the k-th best of them.  k heads are at
+//                  least as good as tau, so each of the k best LOGITS is at least as good as tau — and sits in one of the k ranges
+//                  whose head is; (b) every wave sweeps its own range once more: what is at least as good as tau goes to a
+//                  candidate list (k plus a handful on real logits; never more than k ranges' worth), and exp(l / T - M) is summed
+//                  with the global M (the best head / T); (c) the workgroup whose ticket is last ranks the candidates by counting
+//                  — (value descending, index ascending) is a strict total order over distinct indices — writes those ranked
+//                  below k to out[rank], and adds the waves' sums in fixed order.
+// Round 3's single launch extracted k elements per wave by k rounds of wave-wide maximum and merged the lists by k more rounds
+// in one workgroup: 1.5 us per k (66 us at k = 40, rocprofv3); this form has no loop over k.  NaN-free, finite logits assumed
+// (as k_argmax).  Fewer than k ranges (n < 4096): tau = -inf, every logit is a candidate.
 // ---------------------------------------------------------------------------------------------
-struct TopkWork {  // workspace header; the per-wave lists follow (topk_work_bytes)
-    uint32_t ticket, pad[3];
+constexpr uint32_t TOPK_CAND_CAP = TOPK_MAX * 64 * TOPK_NT;  // k ranges of at most 64 * TOPK_NT logits
+constexpr uint32_t TOPK_LDS_CAP = 4096;                      // heads / candidates staged in LDS (more: read from memory)
+
+struct TopkWork {  // workspace header; heads, per-wave sums and the candidate list follow (topk_work_bytes)
+    uint32_t ticket, n_cand, pad[2];
     float out_v[TOPK_MAX];     // the k largest logits, descending (ties: lower index first)
     uint32_t out_i[TOPK_MAX];
     float M, S;                // max_i(l_i / T), sum_i exp(l_i / T - M)
@@ -306,57 +315,116 @@ struct TopkWork {  // workspace header; the per-wave lists follow (topk_work_byt
 size_t topk_work_bytes(uint32_t n)
 {
     const uint32_t nw = topk_blocks(n) * (TOPK_THREADS / 64);
-    return sizeof(TopkWork) + (size_t)nw * (TOPK_MAX * 8 + 8);
+    return sizeof(TopkWork) + (size_t)nw * 12 + (size_t)TOPK_CAND_CAP * 8;
 }
 size_t topk_out_offset() { return offsetof(TopkWork, out_v); }
 
-__global__ __launch_bounds__(TOPK_THREADS) void k_topk(const float *x, uint32_t n, float temperature, uint32_t k, TopkWork *w)
+struct TopkArrays {
+    float *head_v; uint32_t *head_i; float *ws; float *cand_v; uint32_t *cand_i;
+};
+__device__ __forceinline__ TopkArrays topk_arrays(TopkWork *w, uint32_t nw)
+{
+    TopkArrays a;
+    a.head_v = reinterpret_cast<float *>(w + 1);
+    a.head_i = reinterpret_cast<uint32_t *>(a.head_v + nw);
+    a.ws = reinterpret_cast<float *>(a.head_i + nw);
+    a.cand_v = a.ws + nw;
+    a.cand_i = reinterpret_cast<uint32_t *>(a.cand_v + TOPK_CAND_CAP);
+    return a;
+}
+
+__global__ __launch_bounds__(TOPK_THREADS) void k_topk_heads(const float *x, uint32_t n, TopkWork *w)
 {
     constexpr uint32_t WPB = TOPK_THREADS / 64;
-    __shared__ float sv[WPB];
-    __shared__ uint32_t si[WPB];
-    __shared__ uint32_t is_last;
     const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint32_t nw = gridDim.x * WPB, gw = blockIdx.x * WPB + wid;
-    float *cand_v = reinterpret_cast<float *>(w + 1);                       // [nw][TOPK_MAX]
-    uint32_t *cand_i = reinterpret_cast<uint32_t *>(cand_v + (size_t)nw * TOPK_MAX);
-    float *wm = reinterpret_cast<float *>(cand_i + (size_t)nw * TOPK_MAX);  // [nw] range max of l / T
-    float *ws = wm + nw;                                                     // [nw] range sum of exp(l / T - max)
-    // ---- level 1 ----------------------------------------------------------------------------------------------------------
+    const TopkArrays a = topk_arrays(w, nw);
     const uint32_t cw = (n + nw - 1) / nw, base = gw * cw, end = min(n, base + cw);  // cw <= 64 * TOPK_NT (launch_topk)
-    float v[TOPK_NT];
-    float m = -INFINITY;
+    float bv = -INFINITY;
+    uint32_t bi = 0xFFFFFFFFu;
 #pragma unroll
     for (int j = 0; j < (int)TOPK_NT; j++) {
         const uint32_t i = base + j * 64 + lane;
-        v[j] = i < end ? x[i] : -INFINITY;
-        m = fmaxf(m, v[j] / temperature);  // SamplingUtils.cs:7: l / temperature
+        const float v = i < end ? x[i] : -INFINITY;
+        if (i < end && topk_better(v, i, bv, bi)) { bv = v; bi = i; }
     }
-    m = wave_max(m);
+    wave_best(bv, bi);
+    if (lane == 0) { a.head_v[gw] = bv; a.head_i[gw] = bi; }   // an empty range: (-inf, 0xFFFFFFFF)
+}
+
+// (value descending, index ascending) as ONE unsigned 64-bit order: the float's bits mapped monotonically to an unsigned word in
+// the high half, the complemented index in the low half; a > b as keys <=> topk_better(a, b).  Key 0 is below every real element.
+__device__ __forceinline__ unsigned long long topk_key(float v, uint32_t i)
+{
+    const uint32_t u = __float_as_uint(v + 0.0f);   // -0.0 -> +0.0: equal as floats, so the index decides (topk_better)
+    const uint32_t f = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)f << 32) | (uint32_t)~i;
+}
+__device__ __forceinline__ float topk_key_value(unsigned long long key)
+{
+    const uint32_t f = (uint32_t)(key >> 32);
+    return __uint_as_float((f & 0x80000000u) ? (f & 0x7FFFFFFFu) : ~f);
+}
+__device__ __forceinline__ uint32_t topk_key_index(unsigned long long key) { return ~(uint32_t)key; }
+
+// how many of keys[0, n4) (n4 a multiple of 4, LDS, 16-byte aligned) are greater than `key`: 16-byte reads, eight in flight
+__device__ __forceinline__ uint32_t topk_rank(const unsigned long long *keys, uint32_t n4, unsigned long long key)
+{
+    uint32_t rank = 0;
+#pragma unroll 4
+    for (uint32_t j = 0; j < n4; j += 4) {
+        const ulonglong2 p = *reinterpret_cast<const ulonglong2 *>(keys + j);
+        const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(keys + j + 2);
+        rank += (p.x > key ? 1u : 0u) + (p.y > key ? 1u : 0u) + (q.x > key ? 1u : 0u) + (q.y > key ? 1u : 0u);
+    }
+    return rank;
+}
+
+__global__ __launch_bounds__(TOPK_THREADS) void k_topk_select(const float *x, uint32_t n, float temperature, uint32_t k, TopkWork *w)
+{
+    constexpr uint32_t WPB = TOPK_THREADS / 64;
+    __shared__ __attribute__((aligned(16))) unsigned long long lk[TOPK_LDS_CAP];  // keys of the heads, later (last workgroup) of the candidates
+    __shared__ float sv[WPB];
+    __shared__ unsigned long long s_tau, s_max;
+    __shared__ uint32_t is_last;
+    const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint32_t nw = gridDim.x * WPB, gw = blockIdx.x * WPB + wid;
+    const TopkArrays a = topk_arrays(w, nw);
+    // ---- (a) tau = the k-th best head, M from the best head (heads were written by the launch in front: plain loads) -----------
+    const uint32_t nw4 = (nw + 3) & ~3u;
+    for (uint32_t q = threadIdx.x; q < nw4; q += TOPK_THREADS) lk[q] = q < nw ? topk_key(a.head_v[q], a.head_i[q]) : 0ull;
+    if (threadIdx.x == 0) s_tau = 0ull;   // fewer ranges than outputs: everything is a candidate
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < nw; q += TOPK_THREADS) {
+        const unsigned long long key = lk[q];
+        const uint32_t rank = topk_rank(lk, nw4, key);   // distinct indices -> distinct keys (empty ranges share the lowest one)
+        if (rank == 0) s_max = key;
+        if (nw >= k && rank == k - 1) s_tau = key;
+    }
+    __syncthreads();
+    const unsigned long long tau = s_tau;
+    const float M = topk_key_value(s_max) / temperature;   // SamplingUtils.cs:7: l / temperature, then :37 Max()
+    // ---- (b) this wave's range: candidates and its share of the softmax denominator ------------------------------------------------
+    const uint32_t cw = (n + nw - 1) / nw, base = gw * cw, end = min(n, base + cw);
     float sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < (int)TOPK_NT; j++) sum += (base + j * 64 + lane < end) ? expf(v[j] / temperature - m) : 0.f;  // :38
-    sum = wave_sum(sum);
-    for (uint32_t t = 0; t < k; t++) {
-        float bv = v[0];
-        uint32_t bi = base + lane;
-#pragma unroll
-        for (int j = 1; j < (int)TOPK_NT; j++)
-            if (v[j] > bv) { bv = v[j]; bi = base + j * 64 + lane; }  // strictly greater: the lower index of a tie stays
-        wave_best(bv, bi);
-#pragma unroll
-        for (int j = 0; j < (int)TOPK_NT; j++)
-            if (base + j * 64 + lane == bi) v[j] = -INFINITY;  // the owner retires it
-        if (lane == 0) {
-            __hip_atomic_store(&cand_v[(size_t)gw * TOPK_MAX + t], bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&cand_i[(size_t)gw * TOPK_MAX + t], bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int j = 0; j < (int)TOPK_NT; j++) {
+        const uint32_t i = base + j * 64 + lane;
+        if (i < end) {
+            const float v = x[i];
+            sum += expf(v / temperature - M);                                                  // :38
+            if (topk_key(v, i) >= tau && v > -INFINITY) {                                        // at least as good as tau
+                const uint32_t slot = __hip_atomic_fetch_add(&w->n_cand, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (slot < TOPK_CAND_CAP) {  // cannot overflow: at most k ranges hold candidates (see above)
+                    __hip_atomic_store(&a.cand_v[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&a.cand_i[slot], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
     }
-    if (lane == 0) {
-        __hip_atomic_store(&wm[gw], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&ws[gw], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // every storing wave drains, the block meets, ONE lane takes the ticket (the hand-off of k_argmax)
+    sum = wave_sum(sum);
+    if (lane == 0) __hip_atomic_store(&a.ws[gw], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // every storing wave drains, the workgroup meets, ONE lane takes the ticket (the hand-off of k_argmax)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -365,61 +433,35 @@ __global__ __launch_bounds__(TOPK_THREADS) void k_topk(const float *x, uint32_t 
     }
     __syncthreads();
     if (!is_last) return;
-    // ---- level 2: k-way merge of the nw sorted lists (agent-scope loads: written by other workgroups) -----------------------
-    constexpr int LPT = (TOPK_BLOCKS_MAX * WPB + TOPK_THREADS - 1) / TOPK_THREADS;  // lists per thread
-    float hv[LPT];
-    uint32_t hi[LPT], hp[LPT];
-#pragma unroll
-    for (int q = 0; q < LPT; q++) {
-        const uint32_t list = threadIdx.x + q * TOPK_THREADS;
-        hp[q] = 0;
-        hv[q] = list < nw ? __hip_atomic_load(&cand_v[(size_t)list * TOPK_MAX], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
-        hi[q] = list < nw ? __hip_atomic_load(&cand_i[(size_t)list * TOPK_MAX], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
-    }
-    for (uint32_t t = 0; t < k; t++) {
-        float bv = hv[0];
-        uint32_t bi = hi[0];
-#pragma unroll
-        for (int q = 1; q < LPT; q++)
-            if (topk_better(hv[q], hi[q], bv, bi)) { bv = hv[q]; bi = hi[q]; }
-        wave_best(bv, bi);
-        if (lane == 0) { sv[wid] = bv; si[wid] = bi; }
+    // ---- (c) rank the candidates (agent-scope loads: written by other workgroups) -------------------------------------------------
+    const uint32_t m = min(__hip_atomic_load(&w->n_cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), TOPK_CAND_CAP);
+    if (m <= TOPK_LDS_CAP) {
+        const uint32_t m4 = (m + 3) & ~3u;
+        for (uint32_t c = threadIdx.x; c < m4; c += TOPK_THREADS)
+            lk[c] = c < m ? topk_key(__hip_atomic_load(&a.cand_v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                     __hip_atomic_load(&a.cand_i[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0ull;
         __syncthreads();
-        bv = sv[0];
-        bi = si[0];
-#pragma unroll
-        for (uint32_t q = 1; q < WPB; q++)
-            if (topk_better(sv[q], si[q], bv, bi)) { bv = sv[q]; bi = si[q]; }
-        if (threadIdx.x == 0) { w->out_v[t] = bv; w->out_i[t] = bi; }
-#pragma unroll
-        for (int q = 0; q < LPT; q++) {
-            const uint32_t list = threadIdx.x + q * TOPK_THREADS;
-            if (list < nw && hi[q] == bi && hv[q] == bv) {  // indices are unique: this thread's list holds the winner
-                hp[q]++;
-                const bool more = hp[q] < k;
-                hv[q] = more ? __hip_atomic_load(&cand_v[(size_t)list * TOPK_MAX + hp[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -INFINITY;
-                hi[q] = more ? __hip_atomic_load(&cand_i[(size_t)list * TOPK_MAX + hp[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
-            }
+        for (uint32_t c = threadIdx.x; c < m; c += TOPK_THREADS) {
+            const unsigned long long key = lk[c];
+            const uint32_t rank = topk_rank(lk, m4, key);
+            if (rank < k) { w->out_v[rank] = topk_key_value(key); w->out_i[rank] = topk_key_index(key); }
         }
-        __syncthreads();  // sv / si are rewritten by the next round
+    } else {  // thousands of equal logits around tau: correct, slow (every comparison reads memory)
+        for (uint32_t c = threadIdx.x; c < m; c += TOPK_THREADS) {
+            const float v = __hip_atomic_load(&a.cand_v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t i = __hip_atomic_load(&a.cand_i[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < m && rank < k; j++)
+                rank += topk_better(__hip_atomic_load(&a.cand_v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                    __hip_atomic_load(&a.cand_i[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), v, i) ? 1u : 0u;
+            if (rank < k) { w->out_v[rank] = v; w->out_i[rank] = i; }
+        }
     }
-    // (max, sum of exp): M = max over the ranges, S = sum_w s_w * exp(m_w - M), thread-strided then a fixed tree
-    float M = -INFINITY;
-    for (uint32_t q = threadIdx.x; q < nw; q += TOPK_THREADS) M = fmaxf(M, __hip_atomic_load(&wm[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    M = wave_max(M);
-    if (lane == 0) sv[wid] = M;
-    __syncthreads();
-    M = sv[0];
-#pragma unroll
-    for (uint32_t q = 1; q < WPB; q++) M = fmaxf(M, sv[q]);
-    __syncthreads();
+    // S = the waves' sums, thread-strided then a fixed tree (deterministic)
     float S = 0.f;
-    for (uint32_t q = threadIdx.x; q < nw; q += TOPK_THREADS) {
-        const float mq = __hip_atomic_load(&wm[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float sq = __hip_atomic_load(&ws[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        S += sq * expf(mq - M);
-    }
+    for (uint32_t q = threadIdx.x; q < nw; q += TOPK_THREADS) S += __hip_atomic_load(&a.ws[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     S = wave_sum(S);
+    __syncthreads();
     if (lane == 0) sv[wid] = S;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -428,7 +470,8 @@ __global__ __launch_bounds__(TOPK_THREADS) void k_topk(const float *x, uint32_t 
         for (uint32_t q = 1; q < WPB; q++) S += sv[q];
         w->M = M;
         w->S = S;
-        __hip_atomic_store(&w->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm (stream-ordered with the next launch)
+        __hip_atomic_store(&w->n_cand, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm (stream-ordered with the next launch)
+        __hip_atomic_store(&w->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -437,7 +480,13 @@ hipError_t launch_topk(const float *x, uint32_t n, float temperature, uint32_t k
     if (n == 0 || k == 0 || k > TOPK_MAX || k > n || !(temperature > 0.f)) return hipErrorInvalidValue;
     const uint32_t blocks = topk_blocks(n);
     if ((uint64_t)blocks * TOPK_THREADS * TOPK_NT < n) return hipErrorInvalidValue;  // more logits than TOPK_BLOCKS_MAX blocks hold
-    k_topk<<<blocks, TOPK_THREADS, 0, s>>>(x, n, temperature, k, reinterpret_cast<TopkWork *>(work));
+    static_assert(TOPK_BLOCKS_MAX * (TOPK_THREADS / 64) <= TOPK_LDS_CAP, "the heads are ranked in LDS");
+    // fewer ranges than outputs: every logit is a candidate, which the list must hold
+    if (blocks * (TOPK_THREADS / 64) < k && n > TOPK_CAND_CAP) return hipErrorInvalidValue;
+    k_topk_heads<<<blocks, TOPK_THREADS, 0, s>>>(x, n, reinterpret_cast<TopkWork *>(work));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    k_topk_select<<<blocks, TOPK_THREADS, 0, s>>>(x, n, temperature, k, reinterpret_cast<TopkWork *>(work));
     return hipGetLastError();
 }
 

@@ -87,6 +87,15 @@ struct Model {
     const float *x_last = nullptr;   // where the last enqueued token left the hidden state (m->x, or m->h on the engine path)
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
+    // the BLOCKING calls (nfai_hip_llama_decode_step / _decode_topk) as one graph each: token word in (from pinned host memory),
+    // the token, [the top-k candidate launch,] argmax + error word [+ candidates] out to pinned host memory — the host's share of a
+    // sampled token is one hipGraphLaunch and one hipStreamSynchronize
+    struct SyncGraph {
+        hipGraph_t g = nullptr;
+        hipGraphExec_t exec = nullptr;
+        float temperature = 0.f;
+        uint32_t k = 0;
+    } g_step, g_topk;
     bool prefetch = false, s2_used = false;  // side-stream weight prefetch (NFAI_LLAMA_PREFETCH)
     hipStream_t s2 = nullptr;
     std::vector<hipEvent_t> pf_events;
@@ -763,16 +772,33 @@ NFAI_API int32_t nfai_hip_llama_create(nfai_ctx_t ch, const nfai_llama_desc *des
     return NFAI_OK;
 }
 
+static void drop_sync_graph(Model::SyncGraph &sg)
+{
+    if (sg.exec) { hipGraphExecDestroy(sg.exec); sg.exec = nullptr; }
+    if (sg.g) { hipGraphDestroy(sg.g); sg.g = nullptr; }
+}
+
+static void drop_graphs(Model *m)
+{
+    drop_sync_graph(m->g_step);
+    drop_sync_graph(m->g_topk);
+    if (m->graph_exec) { hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    if (m->graph) { hipGraphDestroy(m->graph); m->graph = nullptr; }
+    if (m->stage_exec) { hipGraphExecDestroy(m->stage_exec); m->stage_exec = nullptr; }
+    if (m->stage_graph) { hipGraphDestroy(m->stage_graph); m->stage_graph = nullptr; }
+}
+
+// One token, blocking; the argmax and the sticky error word of the in-kernel waits land in m->h_pin[0..1].  The slices' workgroups
+// of the attention launch wait for each other (granule hand-off): when one of those bounded waits gives up (codes 0x1000-0x4000:
+// a workgroup was not resident, e.g. another process shares the device), the token's results are not valid — the model switches
+// to the ticket form, which never waits, for good, says so once on stderr, and the SAME token is run again from the same position.
 NFAI_API int32_t nfai_hip_llama_destroy(nfai_model_t h)
 {
     MODEL_OR_FAIL(m, h);
     hipStreamSynchronize(m->ctx->stream);
-    if (m->graph_exec) hipGraphExecDestroy(m->graph_exec);
-    if (m->graph) hipGraphDestroy(m->graph);
+    drop_graphs(m);
     for (hipEvent_t e : m->pf_events) hipEventDestroy(e);
     if (m->s2) hipStreamDestroy(m->s2);
-    if (m->stage_exec) hipGraphExecDestroy(m->stage_exec);
-    if (m->stage_graph) hipGraphDestroy(m->stage_graph);
     for (hipEvent_t e : m->ev) hipEventDestroy(e);
     for (hipEvent_t e : m->prof_rep_ev) if (e) hipEventDestroy(e);
     auto free_t = [](Tensor &t) { if (t.owned && t.ptr) hipFree(t.ptr); };
@@ -931,37 +957,78 @@ NFAI_API int32_t nfai_hip_llama_finalize(nfai_model_t h)
         if (!m->unfused && L.wgate.type != L.wup.type)
             return fail(NFAI_ERR_UNSUPPORTED, "finalize: blk.%zu ffn_gate and ffn_up have different tensor types", i + d.layer_begin);
     }
-    if (m->graph_exec) { hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
-    if (m->graph) { hipGraphDestroy(m->graph); m->graph = nullptr; }
-    if (m->stage_exec) { hipGraphExecDestroy(m->stage_exec); m->stage_exec = nullptr; }
-    if (m->stage_graph) { hipGraphDestroy(m->stage_graph); m->stage_graph = nullptr; }
+    drop_graphs(m);
     if ((rc = build_engine_plans(m))) return rc;
     m->finalized = true;
     return NFAI_OK;
 }
 
-static void drop_graphs(Model *m)
+struct TopkOut { float v[TOPK_MAX]; uint32_t i[TOPK_MAX]; float M, S; };  // the head of the top-k workspace (topk_out_offset())
+static_assert(sizeof(TopkOut) + 16 <= 4096, "pinned staging: words 0..3 (argmax, error word, token in, spare), then the candidates");
+
+// Capture [token word H2D] -> the token -> [top-k launch] -> [argmax, error word(, candidates) D2H].  Errors inside the capture end
+// it before they are reported (a stream left in capture mode would poison every later call).
+static int ensure_sync_graph(Model *m, Model::SyncGraph &sg, bool topk, float temperature, uint32_t k)
 {
-    if (m->graph_exec) { hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
-    if (m->graph) { hipGraphDestroy(m->graph); m->graph = nullptr; }
-    if (m->stage_exec) { hipGraphExecDestroy(m->stage_exec); m->stage_exec = nullptr; }
-    if (m->stage_graph) { hipGraphDestroy(m->stage_graph); m->stage_graph = nullptr; }
+    if (sg.exec && (!topk || (sg.temperature == temperature && sg.k == k))) return NFAI_OK;
+    drop_sync_graph(sg);
+    hipStream_t s = m->ctx->stream;
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int rc = NFAI_OK;
+    hipError_t e = hipMemcpyAsync(m->d_tok, m->h_pin + 2, 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) rc = enqueue_token(m, true);
+    if (e == hipSuccess && !rc && topk) e = launch_topk(m->logits, m->d.V, temperature, k, m->d_topk, s);
+    if (e == hipSuccess && !rc) e = hipMemcpyAsync(m->h_pin, m->d_tok, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && !rc) e = hipMemcpyAsync(m->h_pin + 1, m->d_engerr, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && !rc && topk)
+        e = hipMemcpyAsync(m->h_pin + 4, static_cast<const char *>(m->d_topk) + topk_out_offset(), sizeof(TopkOut), hipMemcpyDeviceToHost, s);
+    hipGraph_t g = nullptr;
+    const hipError_t e2 = hipStreamEndCapture(s, &g);
+    if (rc || e != hipSuccess || e2 != hipSuccess) {
+        if (g) hipGraphDestroy(g);
+        if (rc) return rc;
+        return fail(NFAI_ERR_HIP, "capturing the blocking-step graph failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    }
+    sg.g = g;
+    HIP_TRY(hipGraphInstantiate(&sg.exec, g, nullptr, nullptr, 0));
+    sg.temperature = temperature;
+    sg.k = k;
+    return NFAI_OK;
 }
 
-// One token, blocking; the argmax and the sticky error word of the in-kernel waits land in m->h_pin[0..1].  The slices' workgroups
-// of the attention launch wait for each other (granule hand-off): when one of those bounded waits gives up (codes 0x1000-0x4000:
-// a workgroup was not resident, e.g. another process shares the device), the token's results are not valid — the model switches
-// to the ticket form, which never waits, for good, says so once on stderr, and the SAME token is run again from the same position.
-static int step_blocking(Model *m, uint32_t token)
+// One token, blocking; the argmax and the sticky error word of the in-kernel waits land in m->h_pin[0..1] (with topk: the candidates
+// in m->h_pin[4..]).  The slices' workgroups of the attention launch wait for each other (granule hand-off): when one of those
+// bounded waits gives up (codes 0x1000-0x4000: a workgroup was not resident, e.g. another process shares the device), the token's
+// results are not valid — the model switches to the ticket form, which never waits, for good, says so once on stderr, and the SAME
+// token is run again from the same position.
+static int step_blocking(Model *m, uint32_t token, bool topk = false, float temperature = 0.f, uint32_t k = 0)
 {
     hipStream_t s = m->ctx->stream;
     for (int attempt = 0;; attempt++) {
         const uint32_t pos = m->pos_host;
-        int rc = set_token_async(m, token);
-        if (rc) return rc;
-        if ((rc = run_token(m))) return rc;
-        HIP_TRY(hipMemcpyAsync(m->h_pin, m->d_tok, 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(m->h_pin + 1, m->d_engerr, 4, hipMemcpyDeviceToHost, s));
+        int rc;
+        const bool graphable = m->use_graph && !m->unfused && !m->profiling;
+        if (graphable) {
+            if (m->pos_host >= m->d.C)
+                return fail(NFAI_ERR_KV_FULL, "KV cache full: position %u == capacity %u (the reference would write out of bounds here)",
+                            m->pos_host, m->d.C);
+            Model::SyncGraph &sg = topk ? m->g_topk : m->g_step;
+            if ((rc = ensure_sync_graph(m, sg, topk, temperature, k))) return rc;
+            m->h_pin[2] = token;
+            HIP_TRY(hipGraphLaunch(sg.exec, s));
+            m->pos_host++;
+        } else {
+            if ((rc = set_token_async(m, token))) return rc;
+            if ((rc = run_token(m))) return rc;
+            if (topk) {
+                const hipError_t e = launch_topk(m->logits, m->d.V, temperature, k, m->d_topk, s);
+                if (e != hipSuccess) return fail(NFAI_ERR_HIP, "decode_topk: launch failed: %s", hipGetErrorString(e));
+                HIP_TRY(hipMemcpyAsync(m->h_pin + 4, static_cast<const char *>(m->d_topk) + topk_out_offset(), sizeof(TopkOut), hipMemcpyDeviceToHost, s));
+            }
+            HIP_TRY(hipMemcpyAsync(m->h_pin, m->d_tok, 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(m->h_pin + 1, m->d_engerr, 4, hipMemcpyDeviceToHost, s));
+        }
         HIP_TRY(hipStreamSynchronize(s));
         const uint32_t code = m->h_pin[1];
         if (code == 0) return NFAI_OK;
@@ -1011,37 +1078,11 @@ NFAI_API int32_t nfai_hip_llama_decode_topk(nfai_model_t h, uint32_t token, floa
     if (k == 0 || k > TOPK_MAX || k > m->d.V) return fail(NFAI_ERR_INVALID, "decode_topk: k=%u outside [1, min(%u, V=%u)]", k, TOPK_MAX, m->d.V);
     if (!(temperature > 0.f)) return fail(NFAI_ERR_INVALID, "decode_topk: temperature %g (the reference divides by it, SamplingUtils.cs:7)", temperature);
     if (!m->d_topk) DALLOC(m->d_topk, topk_work_bytes(m->d.V));
-    // the token's graph, the candidate launch and ONE read-back (error word + 8 * TOPK_MAX + 8 bytes) behind each other on the stream:
-    // one host synchronisation per sampled token
-    hipStream_t s = m->ctx->stream;
-    const uint32_t pos = m->pos_host;
-    int rc = set_token_async(m, token);
+    // the token's kernels, the candidate launch and the read-back (error word + 8 * TOPK_MAX + 8 bytes) are ONE graph: one launch
+    // and one host synchronisation per sampled token
+    int rc = step_blocking(m, token, true, temperature, k);
     if (rc) return rc;
-    if ((rc = run_token(m))) return rc;
-    struct TopkOut { float v[TOPK_MAX]; uint32_t i[TOPK_MAX]; float M, S; };
-    static_assert(sizeof(TopkOut) + 16 <= 4096, "pinned staging");
-    TopkOut *out = reinterpret_cast<TopkOut *>(m->h_pin + 4);
-    hipError_t e = launch_topk(m->logits, m->d.V, temperature, k, m->d_topk, s);
-    if (e != hipSuccess) return fail(NFAI_ERR_HIP, "decode_topk: launch failed: %s", hipGetErrorString(e));
-    HIP_TRY(hipMemcpyAsync(m->h_pin + 1, m->d_engerr, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(out, static_cast<const char *>(m->d_topk) + topk_out_offset(), sizeof(TopkOut), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    if (m->h_pin[1] != 0) {
-        // a bounded wait of the attention hand-off gave up: step_blocking's recovery (ticket form, same token again), then the candidates
-        const uint32_t code = m->h_pin[1];
-        if (m->attn_ticket || (code & ~0x7000u) != 0) return engine_failed(m, code);
-        fprintf(stderr, "nfai_hip: an attention launch gave up waiting for a KV slice's partial results (code 0x%x) at position %u; re-running "
-                        "the token on the ticket hand-off, which this model keeps from now on.\n", code, pos);
-        m->attn_ticket = true;
-        drop_graphs(m);
-        HIP_TRY(hipMemsetAsync(m->d_engerr, 0, 4, s));
-        HIP_TRY(hipMemcpyAsync(m->d_pos, &pos, 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        m->h_pin[1] = 0;
-        m->pos_host = pos;
-        if ((rc = step_blocking(m, token))) return rc;
-        return topk_run(m->ctx, m->logits, m->d.V, temperature, k, m->d_topk, ids_out, probs_out);
-    }
+    const TopkOut *out = reinterpret_cast<const TopkOut *>(m->h_pin + 4);
     topk_finish(out->v, out->i, out->M, out->S, temperature, k, ids_out, probs_out);
     return NFAI_OK;
 }
