@@ -3,8 +3,8 @@
 (--pmc FETCH_SIZE, --pmc WRITE_SIZE; with --kernel-trace only), hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (on gfx950
 FETCH_SIZE reports half of a 16 B/lane coalesced stream; WRITE_SIZE is exact).
 
-    tools/pmc_traffic.py f16     -> gpurun_out/round3_pmc_traffic.json       (copied to profiles/; bench.py reads `traffic` from it)
-    tools/pmc_traffic.py q4_k_m  -> gpurun_out/round3_pmc_traffic_q4km.json
+    tools/pmc_traffic.py f16     -> gpurun_out/round4_pmc_traffic.json       (copied to profiles/; bench.py reads `traffic` from it)
+    tools/pmc_traffic.py q4_k_m  -> gpurun_out/round4_pmc_traffic_q4km.json
 
 The profiled command is bench.py at ITS OWN context (512 prompt tokens through the MFMA prefill, then decode steps at
 positions 512...), so the counters belong to the launches the benchmark times.  Runs on the GPU box."""
@@ -18,8 +18,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 quant = sys.argv[1] if len(sys.argv) > 1 else "f16"
-out_json = os.path.join(ROOT, "gpurun_out", "round3_pmc_traffic.json" if quant == "f16" else "round3_pmc_traffic_q4km.json")
-bench = ["python3", os.path.join(ROOT, "bench.py"), "--quant", quant, "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--profile-steps", "0"]
+out_json = os.path.join(ROOT, "gpurun_out", "round4_pmc_traffic.json" if quant == "f16" else "round4_pmc_traffic_q4km.json")
+bench = ["python3", os.path.join(ROOT, "bench.py"), "--quant", quant, "--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--profile-steps", "0", "--configs", "none", "--sample-tokens", "0"]
 vals = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     d = os.path.join(ROOT, "gpurun_out", f"pmc_{ctr}_{quant}")
@@ -57,13 +57,23 @@ def algorithmic_bytes(name):
             return E * F * 2 if u == 4 else E * HD * 2   # Wdown streams K = 8192 (four 1-KiB loads per row and step), Wo K = 3072
         if mode == 0 and m.group(6) == "true":
             return V * E * 2
-    kq = {"nfai::k_gemv_kqt<112, 3, 1, true, 0>": 2 * F * E * 144 // 256, "nfai::k_gemv_kqt<112, 1, 1, false, 1>": E * HD * 144 // 256,
-          "nfai::k_gemv_kqt<112, 1, 2, false, 2>": E * F * 144 // 256, "nfai::k_gemv_kqt<114, 1, 2, false, 2>": E * F * 210 // 256}
-    return kq.get(name)
+    kq = re.match(r"nfai::k_gemv_kqt<(\d+), (\d+), ", name)   # <weight layout (112 Q4_K, 114 Q6_K, 115 q|k Q4_K + v Q6_K), epilogue mode, ...>
+    if kq:
+        wt, mode = int(kq.group(1)), int(kq.group(2))
+        bpw = {112: 144 / 256, 114: 210 / 256}
+        if mode == 3:
+            return int(2 * F * E * bpw[wt])
+        if mode == 2:
+            return int((HD + 2 * KD) * E * bpw[112]) if wt == 112 else int((HD + KD) * E * bpw[112] + KD * E * bpw[114])
+        if mode == 1:   # Wo (K = 3072) and Wdown (K = 8192) differ in the waves-per-tile parameter
+            return int(E * HD * bpw[wt]) if re.match(r"nfai::k_gemv_kqt<\d+, 1, 1,", name) else int(E * F * bpw[wt])
+        if mode == 0:
+            return int(V * E * bpw[wt])
+    return None
 
 
 out = {"command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --quant %s --steps 8 --warmup 2 "
-                  "--no-cpu-baseline --profile-steps 0   (second pass with --pmc WRITE_SIZE; the benchmark's own context of 512 tokens); tools/pmc_traffic.py" % quant,
+                  "--no-cpu-baseline --profile-steps 0 --configs none --sample-tokens 0   (second pass with --pmc WRITE_SIZE; the benchmark's own context of 512 tokens); tools/pmc_traffic.py" % quant,
        "engine": False, "dominant_kernel": None,
        "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE reads exactly 1/2 of a 16 B/lane coalesced stream on gfx950 "
                      "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact",

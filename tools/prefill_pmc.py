@@ -107,6 +107,12 @@ def main():
             if "TCP_TCC_READ_REQ_sum" in vals:
                 e["l1_to_l2_read_tbps_64B"] = round(vals["TCP_TCC_READ_REQ_sum"] * 64 / (d_of(3) * 1e6), 2)
         out["kernels"][f"{k} grid={grid}"] = e
+    # what bench.py's prefill.mfma_util cites: MFMA-busy fraction of the GEMM launches, time-weighted, and per kernel
+    gemms = {k: e for k, e in out["kernels"].items() if k.startswith("k_gemm") and "mfma_util" in e and e.get("avg_us_by_pass")}
+    tot = sum(e["avg_us_by_pass"][0] * e["launches"] for e in gemms.values())
+    out["mfma_busy_frac"] = round(sum(e["mfma_util"] * e["avg_us_by_pass"][0] * e["launches"] for e in gemms.values()) / tot, 4) if tot else None
+    out["mfma_busy_frac_by_kernel"] = {k: {"mfma_busy_frac": e["mfma_util"], "us": e["avg_us_by_pass"][0], "launches": e["launches"],
+                                           "l2_hit": e.get("l2_hit"), "lds_wait_frac_of_wave": e.get("lds_wait_frac_of_wave")} for k, e in gemms.items()}
     path = os.path.join(ROOT, "gpurun_out", tag + ".json")  # copy into profiles/ afterwards (gpurun merges only gpurun_out/)
     json.dump(out, open(path, "w"), indent=1)
     print("wrote", path)
