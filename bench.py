@@ -411,7 +411,8 @@ def run_single(args):
         "config": {"workload": workload,
                    "positions": [pos0, pos0 + args.steps - 1], "kv_capacity": C, "parallelism": "single",
                    "graph": not args.no_graph, "launches_per_block": 2 if engine_on else (4 if args.quant == "f16" else 5),
-                   "launches_per_token": (sum(v[1] for v in prof.values()) // max(1, args.profile_steps)) if prof else None},
+                   "launches_per_token": (sum(v[1] for v in prof.values()) // max(1, args.profile_steps)) if prof else None,
+                   "xcd_row_shares": dict(zip(("shares", "probe_us_equal_shares"), mgr.XcdShares()))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "frac_of_measured_ceiling": achieved / HBM_MEASURED_CEILING_GBPS,
                      "measured_ceiling": HBM_MEASURED_CEILING_GBPS, "traffic": traffic, "traffic_source": traffic_source,

@@ -79,6 +79,13 @@ int32_t nfai_hip_ctx_create_on_stream(int32_t device_ordinal, void *hip_stream, 
 int32_t nfai_hip_ctx_destroy(nfai_ctx_t ctx);
 int32_t nfai_hip_ctx_synchronize(nfai_ctx_t ctx);   /* ≙ vkQueueWaitIdle, VulkanBufferManager.cs:334 */
 int32_t nfai_hip_ctx_device_info(nfai_ctx_t ctx, nfai_device_info *info);
+/* Run record: how the rows of the long weight-streaming launches (lm_head, gate | up) are dealt to the 8 XCDs on this device.  The
+ * first nfai_hip_llama_finalize on a context times a streaming probe (every workgroup reads an equal share of a 768 MB buffer) and
+ * gives the workgroups of each blockIdx % 8 label a share of the rows proportional to their measured rate - a launch ends with its
+ * slowest XCD.  Speed only: every row is computed once, by the same arithmetic, whatever the shares.  shares8 / probe_us8: 8 values
+ * each (may be NULL); zeros before the first finalize or with NFAI_XCD_DEAL=0.  (No reference counterpart: VulkanHelper.cs:149-150
+ * picks a device and never looks at its topology.) */
+int32_t nfai_hip_ctx_xcd_shares(nfai_ctx_t ctx, uint16_t *shares8, float *probe_us8);
 /* hipEvent pair on the context stream (bench.py times the launches with these, not with
  * torch.cuda.Event, which only sees torch's stream). */
 int32_t nfai_hip_timer_begin(nfai_ctx_t ctx);

@@ -53,6 +53,7 @@ SIGNATURES = {
     "nfai_hip_ctx_destroy": [H],
     "nfai_hip_ctx_synchronize": [H],
     "nfai_hip_ctx_device_info": [H, C.POINTER(DeviceInfo)],
+    "nfai_hip_ctx_xcd_shares": [H, C.POINTER(C.c_uint16), C.POINTER(f32)],
     "nfai_hip_timer_begin": [H],
     "nfai_hip_timer_end": [H, C.POINTER(f32)],
     "nfai_hip_buf_alloc": [H, u64, C.POINTER(H)],

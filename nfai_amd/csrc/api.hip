@@ -201,6 +201,19 @@ NFAI_API int32_t nfai_hip_ctx_destroy(nfai_ctx_t h)
     return NFAI_OK;
 }
 
+// How the rows of the long weight-streaming launches are dealt to the XCDs on this context: shares[x] = unit groups per
+// dealing round for the workgroups with blockIdx % 8 == x, probe_us[x] = mean time of such a workgroup in the calibration launch
+// (equal shares).  All zero before the first model is finalised on the context, or when the dealing is off (NFAI_XCD_DEAL=0).
+NFAI_API int32_t nfai_hip_ctx_xcd_shares(nfai_ctx_t h, uint16_t *shares8, float *probe_us8)
+{
+    CTX_OR_FAIL(c, h);
+    for (int x = 0; x < 8; x++) {
+        if (shares8) shares8[x] = c->xcd_state == 1 ? c->xcd_shares[x] : 0;
+        if (probe_us8) probe_us8[x] = c->xcd_state == 1 ? c->xcd_probe_us[x] : 0.f;
+    }
+    return NFAI_OK;
+}
+
 static int canary_check_all(Ctx *c);  // NFAI_HIP_DEBUG_CANARY (below, with nfai_hip_buf_alloc)
 
 NFAI_API int32_t nfai_hip_ctx_synchronize(nfai_ctx_t h)

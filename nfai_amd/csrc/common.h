@@ -48,6 +48,10 @@ unsigned long long *stamp_next_slot(const char *name, uint32_t grid, uint32_t bl
 struct Ctx {
     uint32_t magic = 0x4E464358;  // 'NFCX'
     int device = 0;
+    // per-XCD streaming shares (gemv_xcd_calibrate, first model created on the context): 0 = not yet measured, 1 = measured, 2 = off
+    int xcd_state = 0;
+    uint16_t xcd_shares[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float xcd_probe_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // mean end of a workgroup of each label in the probe launch (equal shares)
     hipStream_t stream = nullptr;
     bool owns_stream = true;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -100,6 +104,11 @@ struct GemvArgs {
     uint32_t rope_dims = 0, H = 0, Hkv = 0, D = 0;
     const uint32_t *pos_dev = nullptr;  // current position (device scalar)
     uint32_t n_cu = 256;
+    // Rows dealt to the XCDs in proportion to how fast each one streams (calibrated once per context: gemv_xcd_calibrate): 8 shares
+    // (rows per dealing round for the workgroups with blockIdx % 8 == x), or nullptr = equal shares.  Speed only: every row is
+    // computed exactly once by the same arithmetic whatever the shares are.  Honoured by the fp16 / fp32 k_gemv for GEMV_PLAIN and
+    // GEMV_GATEUP launches whose grid is a multiple of 8 (the lm_head and the gate | up launch).
+    const uint16_t *xcd_shares = nullptr;
     bool prefetch_only = false;  // side-stream launch that only touches the first two steps of every wave's weights
     // GEMV_QKV_ROPE with RMSNorm only — the per-token prologue folded into the FIRST q|k|v launch of a token (LlamaModel.cs:116 +
     // the RoPE angles RoPEShader.cs:254-256 recomputes per element): begin.on: the activation vector is row tok[0] of the
@@ -137,6 +146,9 @@ inline int ggml_type_of(int t) { return t == NFAI_Q4_K_T16 ? NFAI_Q4_K : (t == N
 
 hipError_t launch_gemv(const GemvArgs &a, hipStream_t s);     // any weight type; K-quants go to launch_gemv_kq / _kqm
 bool gemv_begin_ok(const GemvArgs &a);                         // can this q|k|v launch carry the per-token prologue (GemvArgs::Begin)?
+// Measures how fast the workgroups of each blockIdx % 8 label (= one XCD each) stream from HBM with every CU streaming, and derives
+// the dealing shares of GemvArgs::xcd_shares; nullptr when switched off (NFAI_XCD_DEAL=0) or when the probe could not run.
+const uint16_t *gemv_xcd_calibrate(Ctx *c);
 hipError_t launch_gemv_kq(const GemvArgs &a, hipStream_t s);  // Q4_K (native blocks) / Q6_K (plane layout)
 hipError_t launch_gemv_kqm(const GemvArgs &a, hipStream_t s); // Q4_K_T16: MFMA dot products
 hipError_t launch_repack_q4k_t16(const void *native, void *tiled, uint64_t rows, uint64_t cols, hipStream_t s);

@@ -19,6 +19,9 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <algorithm>
+#include <cmath>
+#include <vector>
 
 namespace nfai {
 
@@ -41,6 +44,9 @@ struct GemvParams {
     uint32_t prefetch_only;  // 1: touch the first two steps of every wave's weights (default cache policy) and exit
     ArgmaxFused am;          // GEMV_PLAIN: first index of the largest output, taken in this launch (am.ticket == nullptr: off)
     BeginParams begin;       // GEMV_QKV_ROPE, split-K form only: the per-token prologue in this launch (begin.on == 0: off)
+    // XD kernels: unit groups dealt to the XCDs by share.  Dealing round r hands out S consecutive groups: label x (blockIdx % 8) gets
+    // the n[x] groups [r * S + off[x], + n[x]); the label's groups in round order are its slots, dealt round-robin to its waves.
+    struct { uint16_t n[8], off[8]; uint32_t S; } xd;
     NFAI_STAMP_PARAM
 };
 
@@ -185,7 +191,7 @@ struct StepWalk {
     }
 };
 
-template <int WT, int MODE, int UPW, int U, bool GUARD, bool NORM, bool BEGIN = false>
+template <int WT, int MODE, int UPW, int U, bool GUARD, bool NORM, bool BEGIN = false, bool XD = false>
 __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
 {
     static_assert(!BEGIN || (MODE == GEMV_QKV_ROPE && NORM), "the per-token prologue rides on the RMSNorm'd q|k|v launch");
@@ -207,9 +213,29 @@ __global__ __launch_bounds__(512) void k_gemv(const GemvParams p)
 #if GEMV_INTERLEAVE
     // groups dealt round-robin over all waves of the launch: every wave (and with it every XCD) reads rows from all over the matrix
     const uint32_t total_groups = (p.NU + UPW - 1) / UPW;
-    const uint32_t ngroups = total_groups > gw ? (total_groups - gw + tw - 1) / tw : 0;
     const uint32_t u_end = p.NU;
-    auto unit_at = [&](uint32_t g, uint32_t q) { return (g * tw + gw) * UPW + q; };
+    // XD: the same, with the XCDs' shares taken from the calibration (an XCD that streams 10 % faster gets 10 % more rows): the
+    // workgroups with blockIdx % 8 == x form one label (one XCD under round-robin placement — speed only, never correctness)
+    const uint32_t xl = blockIdx.x & 7u;
+    const uint32_t xn = XD ? __builtin_amdgcn_readfirstlane((uint32_t)p.xd.n[xl]) : 1u, xoff = XD ? __builtin_amdgcn_readfirstlane((uint32_t)p.xd.off[xl]) : 0u;
+    const uint32_t xw = (gridDim.x >> 3) * nwaves, xlw = (blockIdx.x >> 3) * nwaves + wid;   // waves of the label, this wave among them
+    uint32_t ngroups_;
+    if constexpr (XD) {
+        const uint32_t rounds = total_groups / p.xd.S, rem = total_groups % p.xd.S;
+        const uint32_t slots = rounds * xn + (rem > xoff ? min(rem - xoff, xn) : 0u);
+        ngroups_ = slots > xlw ? (slots - xlw + xw - 1) / xw : 0;
+    } else {
+        ngroups_ = total_groups > gw ? (total_groups - gw + tw - 1) / tw : 0;
+    }
+    const uint32_t ngroups = ngroups_;
+    auto unit_at = [&](uint32_t g, uint32_t q) {
+        if constexpr (XD) {
+            const uint32_t slot = g * xw + xlw;
+            return ((slot / xn) * p.xd.S + xoff + slot % xn) * UPW + q;
+        } else {
+            return (g * tw + gw) * UPW + q;
+        }
+    };
 #else
     const uint32_t u_begin = (uint32_t)(((uint64_t)p.NU * gw) / tw);
     const uint32_t u_end = (uint32_t)(((uint64_t)p.NU * (gw + 1)) / tw);
@@ -712,6 +738,15 @@ static hipError_t launch_one(const GemvParams &p, const GemvPlan &pl, hipStream_
             return hipGetLastError();
         }
     }
+    if constexpr (!GUARD && WT == NFAI_F16 && (MODE == GEMV_PLAIN || MODE == GEMV_GATEUP)) {
+        if (p.xd.S != 0) {  // rows dealt to the XCDs by calibrated share (the lm_head, gate | up): own instantiations
+            if (p.gamma != nullptr)
+                hipLaunchKernelGGL((k_gemv<WT, MODE, UPW, U, GUARD, true, false, true>), dim3(pl.grid), dim3(pl.block), pl.lds_bytes, s, p);
+            else
+                hipLaunchKernelGGL((k_gemv<WT, MODE, UPW, U, GUARD, false, false, true>), dim3(pl.grid), dim3(pl.block), pl.lds_bytes, s, p);
+            return hipGetLastError();
+        }
+    }
     if (p.gamma != nullptr)
         hipLaunchKernelGGL((k_gemv<WT, MODE, UPW, U, GUARD, true>), dim3(pl.grid), dim3(pl.block), pl.lds_bytes, s, p);
     else
@@ -825,12 +860,131 @@ hipError_t launch_gemv(const GemvArgs &a, hipStream_t s)
     if (!pl.ok || (a.argmax_part && pl.grid > ARGMAX_FUSED_MAX_BLOCKS)) return hipErrorInvalidValue;
     p.KC = (a.K + 64 * epl - 1) / (64 * epl);
     if (pl.lds_bytes > 160 * 1024) return hipErrorInvalidValue;
+    p.xd.S = 0;
+    if (a.xcd_shares && !pl.guard && !a.prefetch_only && a.w_type == NFAI_F16 && (a.mode == GEMV_PLAIN || a.mode == GEMV_GATEUP) && pl.grid % 8 == 0 &&
+        (p.NU + pl.upw - 1) / pl.upw >= 8u * pl.grid * (pl.block / 64)) {   // >= 8 groups per wave: a share moves a fraction of a wave's work (at
+                                                                           // gate | up's 4 groups per wave a share is a whole group: measured slower)
+        uint32_t off = 0;
+        bool uniform = true, sane = true;
+        for (int x = 0; x < 8; x++) {
+            p.xd.n[x] = a.xcd_shares[x];
+            p.xd.off[x] = (uint16_t)off;
+            off += a.xcd_shares[x];
+            uniform = uniform && a.xcd_shares[x] == a.xcd_shares[0];
+            sane = sane && a.xcd_shares[x] >= 1 && a.xcd_shares[x] <= 1024;
+        }
+        if (sane && !uniform) p.xd.S = off;   // equal shares: the plain dealing is the same partition, one instantiation fewer in flight
+    }
     {
         static const char *names[] = {"gemv_plain", "gemv_residual", "gemv_qkv_rope", "gemv_gateup"};
         NFAI_STAMP_SET(p, names[a.mode & 3], pl.grid, pl.block);
     }
     if (a.w_type == NFAI_F16) return dispatch_mode<NFAI_F16>(p, pl, a.mode, s);
     return dispatch_mode<NFAI_F32>(p, pl, a.mode, s);
+}
+
+// ---- per-XCD streaming shares ----------------------------------------------------------------------------------------------------
+// A weight-streaming launch ends with its slowest XCD, and the XCDs of this part do not stream equally fast: with equal shares the
+// workgroups of some blockIdx % 8 labels finish a gate | up launch 5-9 % later than others, an lm_head launch up to 20 % later
+// (tools/stamps.py, profiles/round3_stamps_f16.json).  The probe is the same access pattern without the arithmetic: every
+// wave streams an equal number of rows of a buffer far larger than the Infinity Cache with the GEMV's 16-byte non-temporal loads,
+// every workgroup stamps the moment it is done; a label's share is then proportional to 1 / (its workgroups' mean time).
+__global__ __launch_bounds__(512) void k_xcd_probe(const uint8_t *buf, uint64_t bytes_per_wg, unsigned long long *t_begin, unsigned long long *t_end,
+                                                    uint32_t *xcc, uint32_t *sink)
+{
+    // rows of 6 KiB dealt round-robin over all waves of the launch, as k_gemv deals its row groups: every wave — and every XCD —
+    // reads from all over the buffer, so a label's time says how fast its XCD streams, not where its share of the buffer lives
+    constexpr uint32_t ROW = 6144, PIECES = ROW / 1024;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const uint32_t lane = threadIdx.x & 63, nwaves = blockDim.x >> 6, gw = blockIdx.x * nwaves + (threadIdx.x >> 6), tw = gridDim.x * nwaves;
+    const uint64_t rows = bytes_per_wg * gridDim.x / ROW;
+    u32x4 acc = {0u, 0u, 0u, 0u};
+    for (uint64_t r = gw; r + tw < rows; r += 2ull * tw) {   // two rows (12 loads per lane) in flight
+        u32x4 v[2 * PIECES];
+#pragma unroll
+        for (int j = 0; j < (int)PIECES; j++) {
+            v[j] = load_nt16(buf + r * ROW + j * 1024 + lane * 16);
+            v[PIECES + j] = load_nt16(buf + (r + tw) * ROW + j * 1024 + lane * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * (int)PIECES; j++) acc ^= v[j];
+    }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x9E3779B9u) sink[0] = 1;  // keeps the loads
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        t_begin[blockIdx.x] = t0;
+        t_end[blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+        uint32_t id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        xcc[blockIdx.x] = id & 0xFu;
+    }
+}
+
+const uint16_t *gemv_xcd_calibrate(Ctx *c)
+{
+    if (c->xcd_state == 1) return c->xcd_shares;
+    if (c->xcd_state == 2) return nullptr;
+    c->xcd_state = 2;
+    if (const char *env = getenv("NFAI_XCD_DEAL")) {
+        if (atoi(env) == 0) return nullptr;
+    }
+    const uint32_t n_cu = (uint32_t)c->prop.multiProcessorCount;
+    if (n_cu % 8 != 0) return nullptr;
+    const uint64_t per_wg = 3ull << 20, total = per_wg * n_cu;   // 768 MB on 256 CUs: three times the Infinity Cache, ~120 us per pass
+    uint8_t *buf = nullptr;
+    unsigned long long *tb = nullptr;
+    if (hipMalloc(&buf, total) != hipSuccess || hipMalloc(&tb, (size_t)n_cu * 24 + 64) != hipSuccess) {
+        (void)hipGetLastError();
+        if (buf) hipFree(buf);
+        return nullptr;
+    }
+    unsigned long long *te = tb + n_cu;
+    uint32_t *xcc = reinterpret_cast<uint32_t *>(te + n_cu), *sink = xcc + n_cu;
+    std::vector<unsigned long long> hb(n_cu), he(n_cu);
+    std::vector<uint32_t> hx(n_cu);
+    double sum_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int passes = 6;   // the first one warms up (page tables, clocks) and is dropped
+    bool ok = true;
+    for (int it = 0; it < passes && ok; it++) {
+        k_xcd_probe<<<n_cu, 512, 0, c->stream>>>(buf, per_wg, tb, te, xcc, sink);
+        ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess &&
+             hipMemcpy(hb.data(), tb, n_cu * 8, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(he.data(), te, n_cu * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(hx.data(), xcc, n_cu * 4, hipMemcpyDeviceToHost) == hipSuccess;
+        if (!ok || it == 0) continue;
+        unsigned long long first = ~0ull;
+        for (uint32_t b = 0; b < n_cu; b++) first = std::min(first, hb[b]);
+        for (uint32_t b = 0; b < n_cu; b++) sum_us[b & 7] += (double)(he[b] - first) * 0.01;   // s_memrealtime: 100 MHz
+    }
+    hipFree(buf);
+    hipFree(tb);
+    if (!ok) { (void)hipGetLastError(); return nullptr; }
+    // a label must be one XCD for its share to mean anything: every workgroup of a label reports the same XCC id, the labels differ
+    uint32_t label_xcc[8], seen = 0;
+    for (uint32_t b = 0; b < n_cu; b++) {
+        if (b < 8) { label_xcc[b] = hx[b]; seen |= 1u << hx[b]; }
+        else if (hx[b] != label_xcc[b & 7]) return nullptr;
+    }
+    if (seen != 0xFFu) return nullptr;
+    double rate[8], mean = 0.0;
+    for (int x = 0; x < 8; x++) {
+        const double us = sum_us[x] / ((passes - 1) * (n_cu / 8));
+        if (!(us > 1.0)) return nullptr;
+        c->xcd_probe_us[x] = (float)us;
+        rate[x] = 1.0 / us;
+        mean += rate[x] / 8;
+    }
+    static const int base = getenv("NFAI_XCD_BASE") ? atoi(getenv("NFAI_XCD_BASE")) : 40;   // groups per dealing round and label at the mean rate: 2.5 % steps
+    // 1: shares proportional to the probe's rates.  Measured on the lm_head launch (3B fp16, V = 128,256; us per launch, two alternations on
+    // one box, tools/ab_xcd.sh): equal shares 115.4 / 116.3; gain 1: 117.1 / 115.2; 1.5: 113.0 / 114.1; 2: 111.9 / 113.8; 3: 115.2 / 117.3 —
+    // the GEMV's waves lose a little more on a slow XCD than the bare stream of the probe does
+    static const double gain = getenv("NFAI_XCD_GAIN") ? atof(getenv("NFAI_XCD_GAIN")) : 1.75;
+    for (int x = 0; x < 8; x++) {
+        const double r = 1.0 + gain * (rate[x] / mean - 1.0);
+        const long n = lround(base * std::min(1.25, std::max(0.75, r)));
+        c->xcd_shares[x] = (uint16_t)std::max(1L, n);
+    }
+    c->xcd_state = 1;
+    return c->xcd_shares;
 }
 
 // does the first q|k|v launch described by `a` take the per-token prologue (GemvArgs::Begin)?  The fp16 / fp32 GEMV kernels and the

@@ -318,6 +318,7 @@ GemvArgs gemv_base(Model *m, const Tensor &w, const float *x, uint32_t K)
     a.eps = m->d.eps;
     a.n_cu = (uint32_t)m->ctx->prop.multiProcessorCount;
     a.pos_dev = m->d_pos;
+    a.xcd_shares = m->ctx->xcd_state == 1 ? m->ctx->xcd_shares : nullptr;   // measured by nfai_hip_llama_finalize (gemv_xcd_calibrate)
     return a;
 }
 
@@ -958,6 +959,7 @@ NFAI_API int32_t nfai_hip_llama_finalize(nfai_model_t h)
             return fail(NFAI_ERR_UNSUPPORTED, "finalize: blk.%zu ffn_gate and ffn_up have different tensor types", i + d.layer_begin);
     }
     drop_graphs(m);
+    (void)gemv_xcd_calibrate(m->ctx);   // once per context: how fast each XCD streams (rows of the lm_head / gate | up launches are dealt by it)
     if ((rc = build_engine_plans(m))) return rc;
     m->finalized = true;
     return NFAI_OK;

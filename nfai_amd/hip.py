@@ -81,6 +81,13 @@ class HipBufferManager:
         call("nfai_hip_weight_upload", self.handle, ggml_type, n_rows, n_cols, a.ctypes.data_as(C.c_void_p), C.byref(h))
         return DeviceBuffer(self, a.nbytes, adopt=h)
 
+    def XcdShares(self):
+        """(shares[8], probe_us[8]): how the long streaming launches' rows are dealt to the XCDs on this device (zeros: not measured / off)."""
+        import ctypes as C
+        sh, us = (C.c_uint16 * 8)(), (C.c_float * 8)()
+        call("nfai_hip_ctx_xcd_shares", self.handle, sh, us)
+        return list(sh), [round(float(v), 2) for v in us]
+
     def Dispose(self) -> None:  # (:499-509)
         if self.handle:
             call("nfai_hip_ctx_destroy", self.handle)
