@@ -24,7 +24,10 @@ def main():
     shapes = {"3b": ((5120, 3072), (3072, 3072), (16384, 3072), (3072, 8192)), "8b": ((6144, 4096), (4096, 4096), (28672, 4096), (4096, 14336)),
               "1b": ((3072, 2048), (2048, 2048), (16384, 2048), (2048, 8192)),
               # split-K proxies of 3B's Wdown / Wo: the same number of 128 x 96 tiles as two K halves would have, half the K each
-              "splitk-proxy": ((6144, 4096), (6144, 1536))}[os.environ.get("GEMM_MODEL", "3b")]
+              "splitk-proxy": ((6144, 4096), (6144, 1536)),
+              # round 4: Wdown (K = 8192) as FOUR K quarters on 256 x 128 tiles (2 x 24 tiles x 4 = 192 workgroups, half the operand bytes per
+              # workgroup of the 128 x 48 tiling), Wo (K = 3072) as three K thirds; the same workgroup count as columns of one launch
+              "splitk4-proxy": ((12288, 2048), (9216, 1024), (3072, 8192), (3072, 3072))}[os.environ.get("GEMM_MODEL", "3b")]
     for (N, K) in shapes:
         nw = max(2, -(-640 * 2**20 // (N * K * 2))) if cold else 1
         pa = ShaderProperty(mgr, T * K, np.float16)
