@@ -1426,7 +1426,11 @@ NFAI_API int32_t nfai_hip_llama_prefill(nfai_model_t h, const uint32_t *tokens, 
 // rows behind — the loop overwrites the logits of token i with those of token i + 1 and samples once, after the last one (:128-130).
 NFAI_API int32_t nfai_hip_llama_ingest(nfai_model_t h, const uint32_t *tokens, uint32_t n)
 {
-    if (n == 0) return NFAI_OK;   // a one-token prompt has nothing in front of the sampled step
+    if (n == 0) {   // a one-token prompt has nothing in front of the sampled step
+        MODEL_OR_FAIL(m, h);
+        NEED_FINAL(m);
+        return NFAI_OK;
+    }
     return prefill_impl(h, tokens, n, nullptr, false);
 }
 

@@ -81,7 +81,21 @@ class SamplingUtils:
                            rng: np.random.Generator | None = None) -> int:
         """SamplingUtils.cs:14-31 on the (index, probability) pairs `.Take(topK)` leaves (:13) — what
         nfai_hip_llama_decode_topk returns: nucleus cut (the element that crosses topP is kept), renormalise, draw.
-        `rand` stands in for Random.Shared.NextSingle() (:24)."""
+        `rand` stands in for Random.Shared.NextSingle() (:24).  Vectorised: np.cumsum over float32 adds in sequence, exactly the
+        reference's running sums (TopPFromCandidatesLoop is the statement-by-statement form; tests compare the two)."""
+        p = np.asarray(probs, np.float32)
+        cum = np.cumsum(p, dtype=np.float32)                        # cumulative += prob (:17-18)
+        crossed = np.flatnonzero(cum >= np.float32(topP))
+        keep = int(crossed[0]) + 1 if crossed.size else p.size      # the element that crosses topP is kept (:19-20)
+        total = np.float32(np.sum(p[:keep], dtype=np.float64))      # Enumerable.Sum over floats accumulates in double (:23)
+        r = np.float32(rand) if rand is not None else (rng or np.random.default_rng()).random(dtype=np.float32)
+        running = np.cumsum(p[:keep] / total, dtype=np.float32)     # running += prob / total (:27-28)
+        hit = np.flatnonzero(r < running)
+        return int(ids[int(hit[0]) if hit.size else keep - 1])
+
+    @staticmethod
+    def TopPFromCandidatesLoop(ids: np.ndarray, probs: np.ndarray, topP: float = 0.95, rand: float = 0.0) -> int:
+        """The same, one reference statement per line (SamplingUtils.cs:14-31)."""
         cumulative = np.float32(0.0)
         keep = 0
         for p in probs:
@@ -89,8 +103,8 @@ class SamplingUtils:
             keep += 1
             if cumulative >= np.float32(topP):
                 break
-        total = np.float32(np.sum(probs[:keep], dtype=np.float64))  # Enumerable.Sum over floats accumulates in double
-        r = np.float32(rand) if rand is not None else (rng or np.random.default_rng()).random(dtype=np.float32)
+        total = np.float32(np.sum(probs[:keep], dtype=np.float64))
+        r = np.float32(rand)
         running = np.float32(0.0)
         for i in range(keep):
             running = np.float32(running + np.float32(probs[i]) / total)

@@ -211,3 +211,18 @@ def test_oracle_under_address_and_ub_sanitizers():
     r = subprocess.run([os.path.join(here, "san_driver")], capture_output=True, text=True, timeout=300,
                        env={**os.environ, "ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1"})
     assert r.returncode == 0 and "san_driver: ok" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+def test_topp_from_candidates_vectorised_equals_the_loop_and_the_oracle():
+    """The host half of SamplingUtils.TopP (SamplingUtils.cs:14-31) in its two Python forms — np.cumsum and one statement per line — and
+    the oracle's restatement must draw the same token for every `rand`, also when the nucleus is cut at the first or at no element."""
+    from nfai_amd.llama_model import SamplingUtils
+    r = np.random.Generator(np.random.PCG64(77))
+    for trial in range(60):
+        n = int(r.integers(45, 400))
+        logits = (r.standard_normal(n) * float(r.choice([0.3, 1.0, 4.0, 12.0]))).astype(np.float32)
+        for rand in (0.0, 1e-7, 0.013, 0.25, 0.5, 0.77, 0.949, 0.951, 0.9999999):
+            want, ids, probs, _ = orc.topp(logits, 0.5, 0.95, 40, rand)
+            a = SamplingUtils.TopPFromCandidates(ids, probs, 0.95, rand=rand)
+            b = SamplingUtils.TopPFromCandidatesLoop(ids, probs, 0.95, rand=rand)
+            assert a == b == want, (trial, rand, a, b, want)
