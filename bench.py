@@ -446,37 +446,37 @@ def run_single(args):
     if args.sample_tokens > 0:
         n = min(args.sample_tokens, C - 1)
         start = max(0, min(pos0, C - n))
-        tokk = int(toks[-1])
-        m.SetPos(start)
-        m.Step(tokk, want_logits=False)
-        m.SetPos(start)
-        mgr.Synchronize()
-        t1 = time.perf_counter()
-        for _ in range(n):
-            tokk = m.Step(tokk, want_logits=False)[1]
-        dt_g = time.perf_counter() - t1
-        m.SetPos(start)
-        m.StepTopK(tokk)   # allocates the top-k workspace
-        m.SetPos(start)
-        t1 = time.perf_counter()
-        for _ in range(n):
-            ids, _probs = m.StepTopK(tokk)
-            tokk = int(ids[0])
-        dt_k = time.perf_counter() - t1
-        m.SetPos(start)
         rng = np.random.default_rng(7)
-        t1 = time.perf_counter()
-        for _ in range(n):
-            ids, probs = m.StepTopK(tokk)
-            tokk = SamplingUtils.TopPFromCandidates(ids, probs, rng=rng)
-        dt_s = time.perf_counter() - t1
+
+        def host_loop(step):
+            """n blocking calls from position `start`; (tokens/s over the whole loop, tokens/s at the median per-token time)."""
+            m.SetPos(start)
+            tk = step(int(toks[-1]))   # untimed: captures the call's graph, allocates the top-k workspace
+            m.SetPos(start)
+            mgr.Synchronize()
+            per = []
+            for _ in range(n):
+                t1 = time.perf_counter()
+                tk = step(tk)
+                per.append(time.perf_counter() - t1)
+            return n / sum(per), 1.0 / float(np.median(per))
+
+        def sampled(tk):
+            ids, probs = m.StepTopK(tk)
+            return SamplingUtils.TopPFromCandidates(ids, probs, rng=rng)
+
+        g_all, g_med = host_loop(lambda tk: m.Step(tk, want_logits=False)[1])
+        k_all, k_med = host_loop(lambda tk: int(m.StepTopK(tk)[0][0]))
+        s_all, s_med = host_loop(sampled)
         out["sampling_path"] = {
             "tokens": n, "positions": [start, start + n - 1],
-            "blocking_greedy_tokens_per_s": n / dt_g, "decode_topk_tokens_per_s": n / dt_k, "sampling_path_tokens_per_s": n / dt_s,
-            "sampling_vs_blocking_greedy": dt_g / dt_s,
-            "what": "one blocking C-ABI call per token from this Python host: nfai_hip_llama_decode_step (argmax read back) / nfai_hip_llama_decode_topk "
-                    "(token graph + top-40 launch + ONE 528-byte read-back, one synchronisation) / the same + SamplingUtils.TopPFromCandidates "
-                    "(nucleus 0.95 + draw, a Python loop here; the reference's default loop, LlamaModel.cs:130,165)"}
+            "blocking_greedy_tokens_per_s": g_med, "decode_topk_tokens_per_s": k_med, "sampling_path_tokens_per_s": s_med,
+            "sampling_vs_blocking_greedy": s_med / g_med,
+            "whole_loop_tokens_per_s": {"blocking_greedy": g_all, "decode_topk": k_all, "sampling_path": s_all},
+            "what": "one blocking C-ABI call per token from this Python host, tokens/s at the MEDIAN per-token wall time (whole-loop figures beside "
+                    "them): nfai_hip_llama_decode_step (argmax read back) / nfai_hip_llama_decode_topk (token kernels + the two top-40 launches + "
+                    "ONE 528-byte read-back in one hipGraph, one synchronisation) / the same + SamplingUtils.TopPFromCandidates (nucleus 0.95 + "
+                    "draw; the reference's default loop, LlamaModel.cs:130,165)"}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, dims, weights, first_token, gpu_logits, gpu_tokens, n_cmp, one_core=not args.child)
     else:
