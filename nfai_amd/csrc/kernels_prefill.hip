@@ -892,170 +892,9 @@ static hipError_t gemm_launch_glds(const GemmParams &p, uint32_t batch, hipStrea
     return hipGetLastError();
 }
 
-// ---- producer / consumer form (round 4): NO workgroup barrier in the K loop ------------------------------------
-// k_gemm_f16_glds moves all its waves in lock-step through wait -> barrier -> LDS-DMA issue -> multiply (round 3's cycle stamps: on
-// gate|up 512 of 1976 cycles per K tile in MFMA), so the matrix pipes idle while everybody issues.  Here the roles are split:
-//   NL = 4 loader waves (one per SIMD) issue every LDS-DMA of the tile ring and never multiply; loader l publishes "my share of
-//          tile kt has landed" by writing kt + 1 to full[stage][l] behind a counted s_waitcnt vmcnt, and refills the stage of tile
-//          kt - 1 with tile kt + NST - 1 once every consumer has released it;
-//   WM x WN consumer waves (two per SIMD at 4 x 2) never issue a DMA: they poll the stage's four full words (one 16-byte LDS read),
-//          read their fragments, release the stage (free[stage][c] = kt + 1 once the last fragment read has returned) and multiply.
-// The words live in LDS behind the stages; a tile's number only grows, so a stale word can only make a waiter wait.  The two
-// consumer waves of a SIMD drift out of phase by themselves: one multiplies while the other polls and reads.
-template <int BM, int BN, int WM, int WN, int EPI, int NST, int BK = 64, int NL = 4>
-__global__ __launch_bounds__((WM *WN + NL) * 64) void k_gemm_f16_pc(const GemmParams p)
-{
-    constexpr int NC = WM * WN;
-    static_assert((NC == 4 || NC == 8) && (NL == 4 || NL == 8), "four or eight consumer waves, four or eight loaders");
-    constexpr int CH = BK / 8, RPI = 64 / CH, TM = BM / WM / 16, TN = BN / WN / 16;
-    constexpr int NAI = BM / RPI, NBI = BN / RPI;
-    static_assert(NAI % NL == 0 && NBI % NL == 0, "the tile's LDS-DMA pieces are dealt to four loaders");
-    constexpr int AG = NAI / NL, BG = NBI / NL, G = AG + BG;
-    static_assert(AG <= 8 && BG <= 8 && G * (NST - 2) < 64 && NST >= 3, "source pointer arrays; vmcnt is a 6-bit count");
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, B_BASE = NST * A_BYTES, SYNC_BASE = NST * (A_BYTES + B_BYTES);
-    static_assert(EPI != EPI_SILU || BN / WN == 64, "SiLU epilogue pairs columns inside a 64-wide wave slice");
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    typedef __attribute__((address_space(3))) uint8_t lds_u8;
-    volatile uint32_t *fullw = reinterpret_cast<volatile uint32_t *>(lds + SYNC_BASE);  // [NST][8] (the first NL used)
-    volatile uint32_t *freew = fullw + NST * 8;                                          // [NST][8]
-
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
-    uint32_t mt_i, nt_i;
-    {
-        const uint32_t id = blockIdx.x;
-        if (tiles_n % 8 == 0) {
-            const uint32_t xcd = id & 7, slot = id >> 3;
-            nt_i = (slot / tiles_m) * 8 + xcd;
-            mt_i = slot % tiles_m;
-        } else {
-            nt_i = id / tiles_m;
-            mt_i = id % tiles_m;
-        }
-    }
-    const uint32_t m0 = mt_i * BM, n0 = nt_i * BN, batch = blockIdx.y;
-    const uint32_t KT = p.K / BK;
-    // the words start at zero (LDS keeps what the previous kernel left there); no DMA is in flight yet, so a plain barrier is fine
-    if (tid < NST * 16) fullw[tid] = 0u;
-    __syncthreads();
-
-    if (wave >= (uint32_t)NC) {
-        // ---------------------------------------------------------------- loader
-        const uint32_t l = wave - NC;
-        const GLOBAL_AS uint8_t *Ab = (const GLOBAL_AS uint8_t *)(p.A + (uint64_t)batch * p.a_bs);
-        const GLOBAL_AS uint8_t *Bg = (const GLOBAL_AS uint8_t *)p.B[0], *Bu = (const GLOBAL_AS uint8_t *)p.B[1];
-        const uint32_t lrow = lane / CH, lc = lane % CH;
-        const GLOBAL_AS uint8_t *asrc[8], *bsrc[8];
-#pragma unroll
-        for (int i = 0; i < AG; i++) {
-            const uint32_t row = (i * NL + l) * RPI + lrow;
-            asrc[i] = Ab + ((uint64_t)min(m0 + row, p.M - 1) * p.lda + (lc ^ (row & (CH - 1))) * 8) * 2;
-        }
-#pragma unroll
-        for (int i = 0; i < BG; i++) {
-            const uint32_t row = (i * NL + l) * RPI + lrow;
-            const uint32_t chunk = lc ^ (row & (CH - 1));
-            if constexpr (EPI == EPI_SILU) {
-                const uint32_t sl = row >> 6, cc = row & 63, out = n0 / 2 + sl * 32 + (cc & 31);
-                bsrc[i] = (cc < 32 ? Bg : Bu) + ((uint64_t)out * p.ldb + chunk * 8) * 2;
-            } else {
-                const uint32_t n = n0 + row;
-                const uint32_t seg = n < p.seg_end[0] ? 0u : (n < p.seg_end[1] ? 1u : 2u);
-                const uint32_t nrow = n - (seg == 0 ? 0u : p.seg_end[seg - 1]);
-                bsrc[i] = (const GLOBAL_AS uint8_t *)(p.B[seg] + (uint64_t)(batch / p.b_div) * p.b_bs) + ((uint64_t)nrow * p.ldb + chunk * 8) * 2;
-            }
-        }
-        auto issue = [&](uint32_t kt, uint32_t stage) {
-            const uint32_t koff = kt * (BK * 2);
-#pragma unroll
-            for (int i = 0; i < AG; i++) __builtin_amdgcn_global_load_lds(asrc[i] + koff, (lds_u8 *)(lds + stage * A_BYTES + (i * NL + l) * 1024), 16, 0, 0);
-#pragma unroll
-            for (int i = 0; i < BG; i++) __builtin_amdgcn_global_load_lds(bsrc[i] + koff, (lds_u8 *)(lds + B_BASE + stage * B_BYTES + (i * NL + l) * 1024), 16, 0, 0);
-        };
-        // tiles 0 .. NST-2 (past the end: the last tile again, into a stage nobody reads any more — the counts stay uniform)
-#pragma unroll
-        for (int s2 = 0; s2 < NST - 1; s2++) issue(min((uint32_t)s2, KT - 1), s2);
-        uint32_t cur = 0, fill = NST - 1;
-        for (uint32_t kt = 0; kt < KT; kt++) {
-            wait_vmcnt<G * (NST - 2)>();                       // my share of tile kt has landed
-            if (lane == 0) fullw[cur * 8 + l] = kt + 1;
-            if (kt >= 1) {                                     // the stage of tile kt - 1: free once every consumer has read it
-                for (;;) {
-                    const u32x4 f0 = *reinterpret_cast<const volatile u32x4 *>(freew + fill * 8);
-                    u32x4 f1 = f0;
-                    if constexpr (NC == 8) f1 = *reinterpret_cast<const volatile u32x4 *>(freew + fill * 8 + 4);
-                    const uint32_t lo = min(min(min(f0[0], f0[1]), min(f0[2], f0[3])), min(min(f1[0], f1[1]), min(f1[2], f1[3])));
-                    if (__builtin_amdgcn_readfirstlane(lo) >= kt) break;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            issue(min(kt + NST - 1, KT - 1), fill);
-            cur = cur + 1 == NST ? 0 : cur + 1;
-            fill = fill + 1 == NST ? 0 : fill + 1;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the surplus DMAs must not outlive the workgroup's LDS
-        return;
-    }
-    // -------------------------------------------------------------------- consumer
-    const uint32_t wm = wave / WN, wn = wave % WN;
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    uint32_t cur = 0;
-    for (uint32_t kt = 0; kt < KT; kt++) {
-        for (;;) {                                             // every loader's share of tile kt is in the stage
-            const u32x4 f = *reinterpret_cast<const volatile u32x4 *>(fullw + cur * 8);
-            u32x4 f2 = f;
-            if constexpr (NL == 8) f2 = *reinterpret_cast<const volatile u32x4 *>(fullw + cur * 8 + 4);
-            const uint32_t lo = min(min(min(f[0], f[1]), min(f[2], f[3])), min(min(f2[0], f2[1]), min(f2[2], f2[3])));
-            if (__builtin_amdgcn_readfirstlane(lo) >= kt + 1) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-        const uint8_t *la = lds + cur * A_BYTES, *lb = lds + B_BASE + cur * B_BYTES;
-        constexpr int KSTEPS = BK / 32;
-        f16x8 af[KSTEPS][TM], bf[KSTEPS][TN];
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ks++) {
-            const uint32_t chunk = ks * 4 + (lane >> 4);
-#pragma unroll
-            for (int i = 0; i < TM; i++) af[ks][i] = *reinterpret_cast<const f16x8 *>(la + lds_off<CH>(wm * (BM / WM) + i * 16 + (lane & 15), chunk));
-#pragma unroll
-            for (int j = 0; j < TN; j++) bf[ks][j] = *reinterpret_cast<const f16x8 *>(lb + lds_off<CH>(wn * (BN / WN) + j * 16 + (lane & 15), chunk));
-        }
-        // all fragments of the tile are in registers: the stage is released BEFORE the multiplications (the loaders refill it meanwhile)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) freew[cur * 8 + wave] = kt + 1;
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ks++)
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
-        cur = cur + 1 == NST ? 0 : cur + 1;
-    }
-    gemm_store<BM, BN, WM, WN, EPI, TM, TN>(acc, p, m0, n0, wm, wn, lane, batch);
-}
-
-template <int BM, int BN, int WM, int WN, int EPI, int NST, int BK = 64, int NL = 4>
-static hipError_t gemm_launch_pc(const GemmParams &p, uint32_t batch, hipStream_t s)
-{
-    constexpr int LDS = NST * (BM + BN) * BK * 2 + NST * 16 * 4;
-    static_assert(LDS <= 160 * 1024, "LDS of one CU");
-    if (p.K % BK || p.causal != 0 || p.ksplit > 1) return hipErrorInvalidValue;
-    auto kern = k_gemm_f16_pc<BM, BN, WM, WN, EPI, NST, BK, NL>;
-    static bool attr_set = false;
-    if (LDS > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    const uint32_t tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles, batch, 1), dim3((WM * WN + NL) * 64), LDS, s, p);
-    return hipGetLastError();
-}
+// (Round 4 built a producer / consumer form of this kernel — four loader waves issuing every LDS-DMA, the MFMA waves polling per-stage
+// words in LDS, no s_barrier in the K loop — for VERDICT r3 item 7: correct, and 3 % SLOWER than the lock-step kernel on gate|up
+// (61.2 against 59.5 us; profiles/round4_gemm_pc.txt).  Removed again; `git show 09bf429` has the code.)
 
 template <int BM, int BN, int WM, int WN, int BK, int EPI, int KS = 1, int RING = 3>
 static hipError_t gemm_launch(const GemmParams &p, uint32_t batch, hipStream_t s)
@@ -1130,12 +969,6 @@ static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int va
             case 47: if constexpr (EPI != EPI_SILU) return p.N % 96 || p.K % 128 ? hipErrorInvalidValue : gemm_launch_glds<64, 96, 2, 2, EPI, 3, 128, false, 3, 2>(p, batch, s); else break;
             case 48: if constexpr (EPI != EPI_SILU) return p.N % 96 ? hipErrorInvalidValue : gemm_launch_glds<64, 96, 2, 2, EPI, 4, 64, false, 4, 2>(p, batch, s); else break;
             case 30: if constexpr (EPI != EPI_SILU) return p.N % 96 ? hipErrorInvalidValue : gemm_launch_glds<128, 96, 2, 2, EPI, 3, 64, false, 3, 2>(p, batch, s); else break;
-            // round 4: loader waves + MFMA waves, no barrier in the K loop (k_gemm_f16_pc)
-            case 49: return p.N % 128 ? hipErrorInvalidValue : gemm_launch_pc<256, 128, 4, 2, EPI, 3, 64>(p, batch, s);    // 144 KB
-            case 50: return p.N % 128 ? hipErrorInvalidValue : gemm_launch_pc<256, 128, 4, 2, EPI, 6, 32>(p, batch, s);    // six stages of 32
-            case 51: return p.N % 128 ? hipErrorInvalidValue : gemm_launch_pc<128, 128, 2, 2, EPI, 4, 64>(p, batch, s);    // four MFMA waves, 128 KB
-            case 52: return gemm_launch_pc<128, 64, 4, 1, EPI, 5, 64>(p, batch, s);                                        // narrow N: 120 KB
-            case 53: return p.N % 128 ? hipErrorInvalidValue : gemm_launch_pc<256, 128, 4, 2, EPI, 3, 64, 8>(p, batch, s); // eight loaders (two per SIMD)
         }
         return hipErrorInvalidValue;
     }

@@ -10,8 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nfai_amd._lib import call  # noqa: E402
 from nfai_amd.hip import HipBufferManager, ShaderProperty  # noqa: E402
 
-NAMES = {0: "auto", 1: "128x64 reg", 2: "128x128 reg", 3: "128x128 glds2", 4: "128x128 glds3", 5: "128x64 glds2", 6: "128x64 glds3", 7: "128x64 glds4", 8: "128x64 glds3 pipe", 9: "128x64 glds3 bk128 pipe", 10: "128x64 glds2 bk128 pipe", 11: "128x128 glds2 pipe", 12: "128x80 glds3", 13: "128x48 glds3", 14: "128x80 glds4", 15: "128x48 glds4", 16: "128x64 roles a3 b6", 17: "128x64 roles a3 b9", 18: "128x128 roles a3 b4", 19: "128x128 roles a3 b6", 20: "128x80 roles a3 b6", 21: "256x128 w4 glds2", 22: "256x128 w4 glds3", 23: "256x128 w8 glds2", 24: "256x128 w8 glds3", 25: "128x128 ks2 glds3", 26: "128x64 ks2 glds3", 27: "128x80 ks2 glds3", 28: "128x48 ks2 glds3", 29: "128x48 ks2 glds4", 30: "128x96 w2x2 ks2 glds3", 31: "128x48 ks2 glds5", 32: "128x48 bk128 ks2 glds3", 33: "128x48 bk128 ks4 glds3", 34: "128x80 ks2 glds4", 35: "256x128 w8 ks2 glds3", 36: "128x48 ks2 glds6", 37: "128x80 ks2 glds5", 38: "128x128 ks2 glds4", 39: "128x64 bk128 ks2 glds3", 40: "128x80 bk128 ks2 glds3", 41: "128x96 ks2 glds4", 42: "128x64 ks2 glds4", 43: "256x128 w8 glds3 pipe", 44: "256x128 w8 glds2 pipe", 45: "128x48 bk128 ks2 pipe", 46: "128x80 bk128 ks2 pipe", 47: "64x96 2x2 bk128 ks2", 48: "64x96 2x2 ks2 glds4",
-         49: "256x128 pc st3", 50: "256x128 pc bk32 st6", 51: "128x128 pc st4", 52: "128x64 pc st5", 53: "256x128 pc st3 l8"}
+NAMES = {0: "auto", 1: "128x64 reg", 2: "128x128 reg", 3: "128x128 glds2", 4: "128x128 glds3", 5: "128x64 glds2", 6: "128x64 glds3", 7: "128x64 glds4", 8: "128x64 glds3 pipe", 9: "128x64 glds3 bk128 pipe", 10: "128x64 glds2 bk128 pipe", 11: "128x128 glds2 pipe", 12: "128x80 glds3", 13: "128x48 glds3", 14: "128x80 glds4", 15: "128x48 glds4", 16: "128x64 roles a3 b6", 17: "128x64 roles a3 b9", 18: "128x128 roles a3 b4", 19: "128x128 roles a3 b6", 20: "128x80 roles a3 b6", 21: "256x128 w4 glds2", 22: "256x128 w4 glds3", 23: "256x128 w8 glds2", 24: "256x128 w8 glds3", 25: "128x128 ks2 glds3", 26: "128x64 ks2 glds3", 27: "128x80 ks2 glds3", 28: "128x48 ks2 glds3", 29: "128x48 ks2 glds4", 30: "128x96 w2x2 ks2 glds3", 31: "128x48 ks2 glds5", 32: "128x48 bk128 ks2 glds3", 33: "128x48 bk128 ks4 glds3", 34: "128x80 ks2 glds4", 35: "256x128 w8 ks2 glds3", 36: "128x48 ks2 glds6", 37: "128x80 ks2 glds5", 38: "128x128 ks2 glds4", 39: "128x64 bk128 ks2 glds3", 40: "128x80 bk128 ks2 glds3", 41: "128x96 ks2 glds4", 42: "128x64 ks2 glds4", 43: "256x128 w8 glds3 pipe", 44: "256x128 w8 glds2 pipe", 45: "128x48 bk128 ks2 pipe", 46: "128x80 bk128 ks2 pipe", 47: "64x96 2x2 bk128 ks2", 48: "64x96 2x2 ks2 glds4"}
 
 
 def main():
