@@ -130,15 +130,9 @@ public sealed unsafe class HipLlamaModel : IInferenceProvider
         var tokenIds = tokenizer.Tokenize(prompt, addBos: firstInput);                          // :101
         firstInput = false;
         if (PromptPrefill && tokenIds.Count > 1)                                                // :103-126 (only the last output is sampled)
-        {
-            var head = tokenIds.Take(tokenIds.Count - 1).ToArray();
-            fixed (uint* p = head)
-                Native.Check(Native.nfai_hip_llama_ingest(model, p, (uint)head.Length));        // NFAI_ERR_KV_FULL before anything runs
-        }
+            Ingest(tokenIds.Take(tokenIds.Count - 1).ToArray());
         else
-        {
             for (int i = 0; i + 1 < tokenIds.Count; i++) Step(tokenIds[i], sample: false);
-        }
         var tk = Step(tokenIds[^1], sample: true);                                              // :128-130
         yield return tokenizer.Detokenize([tk]);
         while (tk != tokenizer.EosTokenId && !ct.IsCancellationRequested)                       // :134-173
@@ -147,6 +141,14 @@ public sealed unsafe class HipLlamaModel : IInferenceProvider
             if (tk != tokenizer.EosTokenId) yield return tokenizer.Detokenize([tk]);
         }
         await Task.CompletedTask;
+    }
+
+    /// <summary>Prompt tokens whose output is never sampled: K / V rows only, one native call (a plain method: the pinned pointer
+    /// stays out of the iterator above).  NFAI_ERR_KV_FULL is raised before anything runs.</summary>
+    private void Ingest(uint[] tokens)
+    {
+        fixed (uint* p = tokens)
+            Native.Check(Native.nfai_hip_llama_ingest(model, p, (uint)tokens.Length));
     }
 
     private readonly uint[] candidateIds = new uint[TopK];
