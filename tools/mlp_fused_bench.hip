@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <algorithm>
+#include <cmath>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 #define GLOBAL_AS __attribute__((address_space(1)))
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -53,6 +55,7 @@ struct Args {
     const unsigned *epoch;
     unsigned blk, E;
     unsigned *err;
+    unsigned long long *stamps;           // [GRID][8] s_memrealtime marks of wave 0 of every workgroup (fused form, block 0 only)
     unsigned *done;                       // [8][32] arrival counters, one per blockIdx % 8 label on its own 128-byte line (never reset: epoch * 64 arrivals each)
 };
 
@@ -164,8 +167,10 @@ __global__ __launch_bounds__(256) void k_mlp_fused(const Args a)
     extern __shared__ float xs[];
     __shared__ float part[RW][WAVES];
     const unsigned lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     const unsigned tag = a.epoch[0] * 64u + a.blk + 1u;
     gateup_phase<EC, true>(a, xs, tag);
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
     // this wave's whole share of Wdown: requested before anything of the hand-off is looked at
     u32x4 wv[RW][KCH];
     down_issue<RW>(a, wv);
@@ -174,18 +179,24 @@ __global__ __launch_bounds__(256) void k_mlp_fused(const Args a)
     // hand-off forms: sc1 stores, every storing wave's wait, barrier, one agent-scope add)
     asm volatile("s_waitcnt vmcnt(%0)" ::"i"(RW * KCH) : "memory");
     __syncthreads();
+    const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(a.done + (blockIdx.x & 7u) * 32u + a.blk * 256u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // wait until all eight labels have their 64 arrivals of this replay: one lane polls eight words, the wave sleeps in between
     const unsigned target = a.epoch[0] * (GRID / 8);
-    bool ok = false;
-    for (unsigned spin = 0; spin < SPIN_CAP; spin++) {
-        unsigned lo = 0xFFFFFFFFu;
-        if (lane < 8) lo = __hip_atomic_load(a.done + lane * 32u + a.blk * 256u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = lo >= target;
-        if (__all(ok)) break;
-        __builtin_amdgcn_s_sleep(4);
+    // ONE wave per workgroup polls (eight words, long sleeps: a poller beside streaming waves costs them bandwidth); the others wait at the barrier
+    if (wid == 0) {
+        bool ok = false;
+        for (unsigned spin = 0; spin < SPIN_CAP; spin++) {
+            unsigned lo = 0xFFFFFFFFu;
+            if (lane < 8) lo = __hip_atomic_load(a.done + lane * 32u + a.blk * 256u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = lo >= target;
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(16);
+        }
+        if (!__all(ok) && lane == 0) a.err[0] = 1;
     }
-    if (!__all(ok) && lane == 0) a.err[0] = 1;
+    __syncthreads();
+    const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
     // the K slice of the activations this wave multiplies: 8 granules (64 bytes) per lane and chunk, ONE sweep of sc1 loads
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.gran, 0, F * 8, 0x00020000);
     u32x4 gv[KCH][4];
@@ -200,6 +211,7 @@ __global__ __launch_bounds__(256) void k_mlp_fused(const Args a)
 #pragma unroll
         for (int q = 0; q < 4; q++) tags = tags && gv[c][q][1] == tag && gv[c][q][3] == tag;
     if (!__all(tags) && lane == 0) a.err[0] = 2;
+    const unsigned long long t4 = __builtin_amdgcn_s_memrealtime();
     f32x4 xa[KCH][2];
 #pragma unroll
     for (int c = 0; c < KCH; c++) {
@@ -207,6 +219,11 @@ __global__ __launch_bounds__(256) void k_mlp_fused(const Args a)
         xa[c][1] = f32x4{__builtin_bit_cast(float, gv[c][2][0]), __builtin_bit_cast(float, gv[c][2][2]), __builtin_bit_cast(float, gv[c][3][0]), __builtin_bit_cast(float, gv[c][3][2])};
     }
     down_finish<RW>(a, wv, xa, part);
+    if (a.blk == 0 && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long *st = a.stamps + blockIdx.x * 8;
+        st[0] = t0; st[1] = t1; st[2] = t2; st[3] = t3; st[4] = t4; st[5] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 __global__ void k_epoch(unsigned *e) { e[0] += 1; }
@@ -231,6 +248,8 @@ static void run(unsigned E, int blocks, int reps)
     float *x, *xb[2], *act;
     unsigned long long *gran;
     unsigned *epoch, *err, *done;
+    unsigned long long *stamps;
+    CK(hipMalloc(&stamps, GRID * 64));
     CK(hipMalloc(&xb[0], E * 4)); CK(hipMalloc(&xb[1], E * 4)); CK(hipMalloc(&act, F * 4)); CK(hipMalloc(&gran, (size_t)F * 8 * blocks));
     CK(hipMalloc(&epoch, 256)); CK(hipMalloc(&err, 256)); CK(hipMalloc(&x, E * 4)); CK(hipMalloc(&done, (size_t)blocks * 1024)); CK(hipMemset(done, 0, (size_t)blocks * 1024));
     CK(hipMemset(gran, 0, (size_t)F * 8 * blocks)); CK(hipMemset(epoch, 0, 256)); CK(hipMemset(err, 0, 256));
@@ -252,7 +271,7 @@ static void run(unsigned E, int blocks, int reps)
         for (int b = 0; b < blocks; b++) {
             Args a;
             a.Wg = W + per * b; a.Wu = a.Wg + wg; a.Wd = a.Wu + wg;
-            a.x = xb[b & 1]; a.y = xb[(b + 1) & 1]; a.act = act; a.gran = gran + (size_t)F * b; a.epoch = epoch; a.blk = (unsigned)b; a.E = E; a.err = err; a.done = done;
+            a.x = xb[b & 1]; a.y = xb[(b + 1) & 1]; a.act = act; a.gran = gran + (size_t)F * b; a.epoch = epoch; a.blk = (unsigned)b; a.E = E; a.err = err; a.done = done; a.stamps = stamps;
             if (fused) {
                 k_mlp_fused<EC, RW><<<GRID, 256, E * 4, s>>>(a);
             } else {
@@ -280,6 +299,23 @@ static void run(unsigned E, int blocks, int reps)
         printf("E=%u F=%d blocks=%d %s: %.2f us per block (%.0f GB/s)%s\n", E, F, blocks, fused ? "ONE launch (fused)  " : "two launches        ", us[fused],
                per / us[fused] / 1e3, herr == 1 ? "  [a poll gave up!]" : (herr == 2 ? "  [a granule carried the wrong tag!]" : ""));
     }
+    {   // where the fused launch of block 0 spends its time (last replay): marks of wave 0 of every workgroup, relative to the earliest start
+        std::vector<unsigned long long> st(GRID * 8);
+        CK(hipMemcpy(st.data(), stamps, GRID * 64, hipMemcpyDeviceToHost));
+        unsigned long long first = ~0ull;
+        for (int b = 0; b < GRID; b++) first = st[b * 8] < first ? st[b * 8] : first;
+        const char *names[6] = {"start", "gate|up done", "stores acknowledged + barrier", "all arrivals seen", "K slice gathered", "end"};
+        for (int k = 0; k < 6; k++) {
+            std::vector<double> v(GRID);
+            for (int b = 0; b < GRID; b++) v[b] = (double)(st[b * 8 + k] - first) * 0.01;
+            std::sort(v.begin(), v.end());
+            printf("   %-32s median %6.2f us   p90 %6.2f   max %6.2f\n", names[k], v[GRID / 2], v[GRID * 9 / 10], v[GRID - 1]);
+        }
+    }
+    int ndiff = 0;
+    double maxd = 0;
+    for (unsigned i = 0; i < E; i++) { if (out[0][i] != out[1][i]) ndiff++; const double d = fabs((double)out[0][i] - out[1][i]); if (d > maxd) maxd = d; }
+    printf("differing outputs: %d of %u, max |d| = %g\n", ndiff, E, maxd);
     const bool same = memcmp(out[0].data(), out[1].data(), E * 4) == 0;
     printf("outputs %s (y[0] = %g, y[%u] = %g)\n", same ? "bit-identical" : "DIFFER", out[0][0], E - 1, out[0][E - 1]);
 }
