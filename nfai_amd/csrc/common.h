@@ -198,6 +198,7 @@ struct GemmArgs {  // C[M][N] (+R) = alpha * A[M][K] * B[N][K]^T, fp16 operands,
 hipError_t launch_gemm_f16(const GemmArgs &a, hipStream_t s);
 hipError_t launch_gemm_kq(const GemmArgs &a, hipStream_t s);   // dequant-in-LDS GEMM on T16 K-quant weights
 hipError_t launch_f32_to_f16(const float *x, void *y_f16, uint64_t n, hipStream_t s);
+hipError_t launch_sum_slabs(const float *slabs, uint32_t ks, uint64_t n, const float *R, float *C, hipStream_t s);  // C = R + sum of ks slabs of n floats
 hipError_t launch_read_ahead(const void *w, uint64_t bytes, uint32_t n_cu, hipStream_t s);  // side-stream hint: the next GEMM's weights -> Infinity Cache
 hipError_t launch_rmsnorm_rows(const float *x, const float *g, void *y_f16, uint32_t T, uint32_t E, float eps, hipStream_t s);
 hipError_t launch_rope_store_rows(const float *q, const float *k, const float *v, void *qh_f16, void *kc, void *vc, int kv_f16,

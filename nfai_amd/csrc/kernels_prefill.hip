@@ -1262,6 +1262,24 @@ hipError_t launch_gemm_f16(const GemmArgs &a, hipStream_t s)
     return gemm_pick<EPI_F32>(p, batch, n_cu, a.variant, s);
 }
 
+// C = R + slab 0 + slab 1 + ... (fixed order): the combine of a projection whose K range was split over workgroups (short prompts,
+// llama.hip prefill_chunk); n = M * N elements per slab, a multiple of 4.
+__global__ __launch_bounds__(256) void k_sum_slabs(const float *slabs, uint32_t ks, uint64_t n, const float *R, float *C)
+{
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4 v = R ? *reinterpret_cast<const f32x4 *>(R + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (uint32_t z = 0; z < ks; z++) v += *reinterpret_cast<const f32x4 *>(slabs + (uint64_t)z * n + i);
+    *reinterpret_cast<f32x4 *>(C + i) = v;
+}
+
+hipError_t launch_sum_slabs(const float *slabs, uint32_t ks, uint64_t n, const float *R, float *C, hipStream_t s)
+{
+    if (n == 0 || n % 4 || ks == 0) return hipErrorInvalidValue;
+    k_sum_slabs<<<(uint32_t)((n / 4 + 255) / 256), 256, 0, s>>>(slabs, ks, n, R, C);
+    return hipGetLastError();
+}
+
 // fp32 rows -> fp16 (the attention output on its way into the Wo GEMM)
 __global__ void k_f32_to_f16(const float *x, _Float16 *y, uint64_t n)
 {

@@ -1169,6 +1169,31 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
             g.R = R ? R + col : nullptr;
             g.n_cu = (uint32_t)m->ctx->prop.multiProcessorCount;
             hipError_t e;
+            // Short prompts (17 .. 128 rows; the provider path's templated chat prompts): one row of 128 x BN tiles is N / BN = 48-64
+            // workgroups walking all of K — a quarter of the chip, 45 us for Wdown at 3B.  The K range is split over `ks` launches' worth of
+            // workgroups instead (the GEMM's batch dimension: batch z multiplies columns [z K / ks, (z + 1) K / ks) of A and W into slab
+            // z) and k_sum_slabs adds residual + slabs in order (deterministic).  One tensor, fp16, fp32 output only (Wo, Wdown).
+            static const bool split_short = !(getenv("NFAI_PREFILL_SPLITK_SHORT") && atoi(getenv("NFAI_PREFILL_SPLITK_SHORT")) == 0);
+            if (split_short && seg[first]->type == NFAI_F16 && nseg == 1 && T > 16 && T <= 128 && g.N % 64 == 0 && C != nullptr) {
+                const uint64_t tiles = g.N / 64, n_cu = g.n_cu, sc_floats = (uint64_t)d.H * w.T * w.Spad;
+                uint32_t best = 1;
+                uint64_t best_cost = ((tiles + n_cu - 1) / n_cu) * K;
+                for (uint32_t ks : {2u, 3u, 4u, 6u, 8u}) {
+                    if (K % (ks * 128) || K / ks < 512 || (uint64_t)ks * T * g.N > sc_floats) continue;
+                    const uint64_t cost = ((tiles * ks + n_cu - 1) / n_cu) * (K / ks);
+                    if (cost < best_cost) { best = ks; best_cost = cost; }
+                }
+                if (best > 1) {
+                    GemmArgs gs = g;
+                    gs.batch = best; gs.K = K / best; gs.a_bs = K / best; gs.b_bs = K / best; gs.c_bs = (uint64_t)T * g.N;
+                    gs.C = w.SC; gs.R = nullptr;
+                    if ((e = launch_gemm_f16(gs, s)) != hipSuccess) return e;
+                    if ((e = launch_sum_slabs(w.SC, best, (uint64_t)T * g.N, g.R, static_cast<float *>(g.C), s)) != hipSuccess) return e;
+                    col += g.N;
+                    first = last + 1;
+                    continue;
+                }
+            }
             if (seg[first]->type == NFAI_F16) {
                 e = launch_gemm_f16(g, s);
             } else {
