@@ -972,6 +972,11 @@ static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int va
         }
         return hipErrorInvalidValue;
     }
+    // Short prompts (<= 64 rows): a 128-row tile stages 128 activation rows (the rows past M clamped: L2 hits, but the same bytes through
+    // the CU's load path) beside 48-80 weight rows — the activations are most of what a workgroup takes in.  64-row tiles halve that
+    // (four waves of 16 x 64, four stages of 16 KB).  NFAI_GEMM_M64_SHORT=0: the 128-row tiles at every row count.
+    static const bool m64_short = !(getenv("NFAI_GEMM_M64_SHORT") && atoi(getenv("NFAI_GEMM_M64_SHORT")) == 0);
+    if (m64_short && p.M <= 64 && p.causal == 0 && p.ksplit == 1) return gemm_launch_glds<64, 64, 4, 1, EPI, 4>(p, batch, s);
     static const int env_big = getenv("NFAI_GEMM_BIG") ? atoi(getenv("NFAI_GEMM_BIG")) : 1;
     const uint64_t big_tiles = (uint64_t)((p.M + 127) / 128) * (p.N / 128) * batch;
     if constexpr (EPI == EPI_F32) {
@@ -1067,112 +1072,10 @@ static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int va
     return gemm_launch<128, 64, 4, 1, 64, EPI>(p, batch, s);
 }
 
-// ---- skinny GEMM: very short prompts and chunk tails (M <= 16 rows; written for M <= 64) ---------------------------------------------------------------------------------------
-// The provider path hands the prompt to the prefill (nfai_hip_llama_ingest), and a chat prompt is 20-100 tokens: at M <= 64 the tiled
-// kernels above have N / BN = 64-128 workgroups with 24-64 K tiles each — a quarter of the chip, latency-bound (a 39-token prompt took 3.4 ms
-// at 3B, as long as 330 tokens; the weights alone stream in 1.2 ms).  At these row counts a projection is a weight STREAM with an MFMA
-// behind it, so this kernel is shaped like the decode GEMV:
-//   workgroup = TN x 16 weight rows (TN = 1: 192-320 workgroups on the narrow projections; TN = 4 for gate | up: the 64-wide slice of 32
-//               gate + 32 up rows the SiLU epilogue pairs, 256 workgroups), eight waves that split K;
-//   B (weights): each lane loads 16 bytes of its weight row straight into the MFMA's B fragment (non-temporal, UN k-steps in flight);
-//               a row's consecutive 64-byte pieces are consecutive k-steps, so every 128-byte line is fetched from HBM once;
-//   A (activations, M x K fp16, at most 1 MB: L2-resident): 16-byte loads straight into the A fragments;
-//   the waves' accumulators meet in LDS in fixed wave order (deterministic), one 16-row block at a time, and the epilogue is gemm_store —
-//   the same code as the tiled kernels (fp32 + residual, RoPE + q / KV-cache stores, SiLU * up).
-// Same operand rounding as the tiled kernels (fp16 operands, fp32 accumulate); the summation order over K differs (eight partial sums).
-template <int MT, int TN, int EPI>
-__global__ __launch_bounds__(512) void k_gemm_skinny(const GemmParams p)
-{
-    constexpr int NW = 8, UN = TN == 1 ? 8 : 4;   // k-steps (32 deep) requested together (K = 3072: a wave's whole range in two rounds)
-    static_assert(EPI != EPI_SILU || TN == 4, "the SiLU epilogue pairs 32 gate with 32 up rows");
-    __shared__ f32x4 red[NW][TN][64];
-    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t n0 = blockIdx.x * (TN * 16), l15 = lane & 15, kg = lane >> 4;
-    const GLOBAL_AS _Float16 *arow[MT], *brow[TN];
-#pragma unroll
-    for (int i = 0; i < MT; i++) arow[i] = (const GLOBAL_AS _Float16 *)p.A + (uint64_t)min((uint32_t)i * 16 + l15, p.M - 1) * p.lda + kg * 8;
-#pragma unroll
-    for (int j = 0; j < TN; j++) {
-        const uint32_t row = j * 16 + l15;
-        if constexpr (EPI == EPI_SILU) {
-            const uint32_t out = n0 / 2 + (row & 31);   // columns 0-31 of the slice: gate rows, 32-63: the up rows of the same outputs
-            brow[j] = (const GLOBAL_AS _Float16 *)(row < 32 ? p.B[0] : p.B[1]) + (uint64_t)out * p.ldb + kg * 8;
-        } else {
-            const uint32_t n = n0 + row;
-            const uint32_t seg = n < p.seg_end[0] ? 0u : (n < p.seg_end[1] ? 1u : 2u);
-            brow[j] = (const GLOBAL_AS _Float16 *)p.B[seg] + (uint64_t)(n - (seg == 0 ? 0u : p.seg_end[seg - 1])) * p.ldb + kg * 8;
-        }
-    }
-    f32x4 acc[MT][TN];
-#pragma unroll
-    for (int i = 0; i < MT; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // this wave's k-steps: [s0, s1), whole groups of UN (a group past the end is skipped, a partial one multiplies zeros)
-    const uint32_t ksteps = p.K / 32, groups = (ksteps + UN - 1) / UN, gper = (groups + NW - 1) / NW;
-    const uint32_t g0 = wave * gper, g1 = min(groups, g0 + gper);
-    for (uint32_t g = g0; g < g1; g++) {
-        f16x8 bf[UN][TN], af[UN][MT];
-#pragma unroll
-        for (int u = 0; u < UN; u++) {
-            const uint32_t st = min(g * UN + u, ksteps - 1);   // clamped: the load is unconditional, a step past the end is zeroed below
-#pragma unroll
-            for (int j = 0; j < TN; j++) bf[u][j] = __builtin_bit_cast(f16x8, __builtin_nontemporal_load(reinterpret_cast<const GLOBAL_AS u32x4 *>(brow[j] + (uint64_t)st * 32)));
-#pragma unroll
-            for (int i = 0; i < MT; i++) af[u][i] = *reinterpret_cast<const GLOBAL_AS f16x8 *>(arow[i] + (uint64_t)st * 32);
-        }
-#pragma unroll
-        for (int u = 0; u < UN; u++) {
-            if (g * UN + u >= ksteps) {
-#pragma unroll
-                for (int j = 0; j < TN; j++) bf[u][j] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            }
-#pragma unroll
-            for (int i = 0; i < MT; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u][i], bf[u][j], acc[i][j], 0, 0, 0);
-        }
-    }
-    // the eight partial sums of one 16-row block at a time: wave 0 + wave 1 + ... (fixed order), then the block's epilogue by wave i % 8
-#pragma unroll
-    for (int i = 0; i < MT; i++) {
-#pragma unroll
-        for (int j = 0; j < TN; j++) red[wave][j][lane] = acc[i][j];
-        __syncthreads();
-        if (wave == (uint32_t)(i % NW)) {
-            f32x4 sum[1][TN];
-#pragma unroll
-            for (int j = 0; j < TN; j++) {
-                f32x4 v = red[0][j][lane];
-#pragma unroll
-                for (int w = 1; w < NW; w++) v += red[w][j][lane];
-                sum[0][j] = v;
-            }
-            gemm_store<16, TN * 16, 1, 1, EPI, 1, TN>(sum, p, (uint32_t)i * 16, n0, 0, 0, lane, 0);
-        }
-        __syncthreads();
-    }
-}
-
-template <int TN, int EPI>
-static hipError_t gemm_launch_skinny(const GemmParams &p, hipStream_t s)
-{
-    const uint32_t grid = p.N / (TN * 16), mt = (p.M + 15) / 16;
-    // one 16-row block only.  With more, every workgroup re-reads M x K activations in 64-byte pieces per row (an MFMA fragment's
-    // shape) — eight times the weight bytes at 64 rows: measured 3.64 / 4.57 ms per 39- / 64-token prompt at 3B against 3.38 / 3.46 for the
-    // tiled kernels, while 1 / 8 / 16 tokens take 2.24 / 2.30 / 2.54 ms against 3.31 / 3.26 / 3.27 (tools/ingest_latency.py).
-    if (mt != 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_gemm_skinny<1, TN, EPI>), dim3(grid), dim3(512), 0, s, p);
-    return hipGetLastError();
-}
-
-// M <= 16, one batch, dense: the skinny kernel (NFAI_GEMM_SKINNY=0: the tiled kernels at every row count)
-static bool gemm_skinny_ok(const GemmParams &p, uint32_t batch, int variant)
-{
-    static const bool on = !(getenv("NFAI_GEMM_SKINNY") && atoi(getenv("NFAI_GEMM_SKINNY")) == 0);
-    return on && variant == 0 && p.M <= 16 && batch == 1 && p.causal == 0 && p.ksplit == 1 && p.K % 32 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 &&
-           (p.seg_end[0] | p.seg_end[1] | p.N) % 16 == 0;
-}
+// (Round 4 also built a "skinny" GEMM for <= 16 rows — shaped like the decode GEMV: 16 weight rows per workgroup, eight waves splitting K,
+// weights straight into the MFMA's B fragments — and a 64-row form of it with K splits and a ticketed combine.  The 64-row tiles below plus
+// the K split of Wo / Wdown (llama.hip) are as fast or faster at every row count (1 / 8 / 16 tokens at 3B: 2.34 / 2.34 / 2.34 ms against
+// 2.34 / 2.40 / 2.50), so both were removed: `git show 9ef9490:nfai_amd/csrc/kernels_prefill.hip`, profiles/round4_ingest_latency*.txt.)
 
 // cos / sin of positions pos0 .. pos0+T-1 for the pairs below rope_dims (the arithmetic of k_rope_store_tiles: theta = freq * pos in
 // fp32, cosf / sinf), once per prompt chunk: every block's q | k | v epilogue reads it.
@@ -1200,6 +1103,9 @@ hipError_t launch_rope_table(const float *freqs, uint32_t pos0, uint32_t T, uint
 // the q | k | v projection with the RoPE epilogue: the narrow configurations only (N = (H + 2 Hkv) D is a few thousand columns)
 static hipError_t gemm_pick_rope(GemmParams &p, uint32_t n_cu, hipStream_t s)
 {
+    static const bool m64_short = !(getenv("NFAI_GEMM_M64_SHORT") && atoi(getenv("NFAI_GEMM_M64_SHORT")) == 0);
+    if (m64_short && p.M <= 64)   // short prompts: 64-row tiles (gemm_pick)
+        return p.N % 80 == 0 ? gemm_launch_glds<64, 80, 4, 1, EPI_ROPE, 4>(p, 1, s) : gemm_launch_glds<64, 64, 4, 1, EPI_ROPE, 4>(p, 1, s);
     const uint64_t tm = (p.M + 127) / 128;
     auto cost = [&](uint32_t bn) { return ((tm * (p.N / bn) + n_cu - 1) / n_cu) * (128 + bn); };
     uint32_t best = 64;
@@ -1243,16 +1149,13 @@ hipError_t launch_gemm_f16(const GemmArgs &a, hipStream_t s)
         if (a.n0 != r.H * r.D || a.n1 != r.Hkv * r.D || a.N != (r.H + 2 * r.Hkv) * r.D) return hipErrorInvalidValue;
         if ((p.seg_end[0] | p.seg_end[1] | a.N) % 16) return hipErrorInvalidValue;
         p.rope = r;
-        if (gemm_skinny_ok(p, batch, a.variant)) return gemm_launch_skinny<1, EPI_ROPE>(p, s);
         return gemm_pick_rope(p, n_cu, s);
     }
     if (a.epi == EPI_SILU) {
         // N counts gate + up columns; the two segments must be equally long and the output is [M][N/2] fp16
         if (!a.B1 || a.n0 * 2 != a.N || a.R || batch != 1) return hipErrorInvalidValue;
-        if (gemm_skinny_ok(p, batch, a.variant)) return gemm_launch_skinny<4, EPI_SILU>(p, s);
         return gemm_pick<EPI_SILU>(p, batch, n_cu, a.variant, s);
     }
-    if (a.epi == EPI_F32 && gemm_skinny_ok(p, batch, a.variant)) return gemm_launch_skinny<1, EPI_F32>(p, s);
     // a segment boundary inside a 128-wide tile is not supported by the wide configuration: fall back
     if ((p.seg_end[0] | p.seg_end[1]) % 128) {
         if (a.epi == EPI_F16) return a.R ? hipErrorInvalidValue : gemm_launch<128, 64, 4, 1, 64, EPI_F16>(p, batch, s);

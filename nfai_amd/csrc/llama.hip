@@ -1174,7 +1174,7 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
             // workgroups instead (the GEMM's batch dimension: batch z multiplies columns [z K / ks, (z + 1) K / ks) of A and W into slab
             // z) and k_sum_slabs adds residual + slabs in order (deterministic).  One tensor, fp16, fp32 output only (Wo, Wdown).
             static const bool split_short = !(getenv("NFAI_PREFILL_SPLITK_SHORT") && atoi(getenv("NFAI_PREFILL_SPLITK_SHORT")) == 0);
-            if (split_short && seg[first]->type == NFAI_F16 && nseg == 1 && T > 16 && T <= 128 && g.N % 64 == 0 && C != nullptr) {
+            if (split_short && seg[first]->type == NFAI_F16 && nseg == 1 && T <= 128 && g.N % 64 == 0 && C != nullptr) {
                 const uint64_t tiles = g.N / 64, n_cu = g.n_cu, sc_floats = (uint64_t)d.H * w.T * w.Spad;
                 uint32_t best = 1;
                 uint64_t best_cost = ((tiles + n_cu - 1) / n_cu) * K;
