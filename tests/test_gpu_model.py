@@ -456,8 +456,9 @@ def test_prefill_mfma_matches_token_by_token(mgr, dims, n, chunk):
     m.Dispose()
 
 
-@pytest.mark.parametrize("dims,chunk", [(synth.LLAMA_32_3B, 512), (synth.LLAMA_32_3B, 256), (synth.LLAMA_31_8B, 512), (synth.LLAMA_32_1B, 512)],
-                         ids=["3b-512", "3b-2x256", "8b-512", "1b-512"])
+@pytest.mark.parametrize("dims,chunk", [(synth.LLAMA_32_3B, 512), (synth.LLAMA_32_3B, 256), (synth.LLAMA_31_8B, 512), (synth.LLAMA_32_1B, 512),
+                                        (synth.LLAMA_32_3B, -39), (synth.LLAMA_32_1B, -100), (synth.LLAMA_31_8B, -7)],
+                         ids=["3b-512", "3b-2x256", "8b-512", "1b-512", "3b-short-39", "1b-short-100", "8b-short-7"])
 def test_prefill_full_width_block(mgr, dims, chunk):
     """BASELINE config 3's prefill leg at its real size: ONE block at the published widths (vocabulary cut to 4096 rows so the
     oracle stays fast), T = 512 prompt tokens through the MFMA prefill — here gemm_pick takes the 128 x 128 direct-to-LDS
@@ -468,8 +469,11 @@ def test_prefill_full_width_block(mgr, dims, chunk):
     from nfai_amd.llama_model import LlamaModel
     d1 = replace(dims, L=1, V=4096, name=dims.name + "-1blk")
     w = synth.make_weights(d1, seed=33)
-    n, C = 512, 528
-    m = LlamaModel(mgr, synth.make_metadata(d1), w, C, max_batch=chunk)
+    # chunk < 0: a SHORT prompt of -chunk tokens in one call (what the provider path's RunAsync hands to nfai_hip_llama_ingest): at <= 64 rows
+    # the 64-row tiles, at <= 128 rows the K range of Wo / Wdown split over the chip + k_sum_slabs, at the published widths
+    n = 512 if chunk > 0 else -chunk
+    C = n + 16
+    m = LlamaModel(mgr, synth.make_metadata(d1), w, C, max_batch=max(chunk, 128))
     ref = orc.OracleLlama(odesc(d1, C), w)
     toks = synth.make_tokens(d1, n, seed=14)
     for t in toks[:-1]:
@@ -480,7 +484,7 @@ def test_prefill_full_width_block(mgr, dims, chunk):
     tol = 2e-2 * max(1.0, float(np.abs(want).max()))
     assert np.abs(got - want).max() <= tol, np.abs(got - want).max()
     assert int(np.argmax(got)) == orc.argmax(want)
-    for pos in (0, 255, 256, n - 1):
+    for pos in sorted({0, min(255, n - 1), min(256, n - 1), n - 1}):
         np.testing.assert_allclose(m.ReadKV(0, False, pos), ref.kcache(0)[pos], rtol=0, atol=2e-2)
         np.testing.assert_allclose(m.ReadKV(0, True, pos), ref.vcache(0)[pos], rtol=0, atol=2e-2)
     # the hidden state of the last prompt token (what the output norm + lm_head consumed)
