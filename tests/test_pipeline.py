@@ -295,3 +295,32 @@ def test_schedule_ticks_properties(world, n_steps):
                 assert v[0][2] == firsts[slot] and all(c[2] is None for c in v[1:])
     if world == 1:
         assert sum(1 for c in stages[0].calls if c[0] == "last_from_first") == n_steps
+
+
+def test_bench_helpers_stage_share_types_and_child_commands():
+    """bench.py's host logic that needs no GPU: a stage share (--stage-blocks) names its blocks blk.0.. but takes the tensor types of its
+    GLOBAL block indices (llama.cpp's Q4_K_M "more bits" rule); every configs[] child command parses with bench.py's own parser."""
+    import sys
+    import bench as B
+    dims = synth.LLAMA_31_8B
+    for l in range(dims.L):
+        want = B.Q6_K if B.use_more_bits(l, dims.L) else B.Q4_K
+        assert B.tensor_type(f"blk.{l}.ffn_down.weight", dims, "q4_k_m") == want
+        for b0 in (0, 8, 28):
+            if b0 <= l < b0 + 4:
+                assert B.tensor_type(f"blk.{l - b0}.ffn_down.weight", dims, "q4_k_m", b0, dims.L) == want
+    assert all(B.tensor_type(f"blk.{i}.attn_v.weight", dims, "q4_k_m", 28, 32) == B.Q6_K for i in range(4))   # the last four blocks
+    assert B.tensor_type("output.weight", dims, "q4_k_m") == B.Q6_K and B.tensor_type("blk.3.attn_q.weight", dims, "q4_k_m") == B.Q4_K
+    assert B.tensor_type("blk.3.attn_q.weight", dims, "f16") == 1
+    argv = sys.argv
+    try:
+        for label, extra in B.CHILD_CONFIGS:
+            sys.argv = ["bench.py", "--child", "--configs", "none", "--gpus", "1", "--steps", "64", "--warmup", "8", "--context", "512",
+                        "--sample-tokens", "0", "--profile-steps", "3"] + extra
+            a = B.parse()
+            assert a.child and a.configs == "none" and a.model in synth.BY_NAME and a.quant in ("f16", "q4_k_m"), label
+            if a.stage_blocks:
+                b0, b1 = (int(v) for v in a.stage_blocks.split(":"))
+                assert 0 <= b0 < b1 <= synth.BY_NAME[a.model].L
+    finally:
+        sys.argv = argv
