@@ -340,6 +340,21 @@ def test_topk_sampling_path(mgr):
     ids, probs = m.StepTopK(tok, 0.5, 40)
     np.testing.assert_array_equal(np.sort(ids), np.sort(orc.topp(m.Read(4, dims.V), 0.5, 0.95, 40, 0.0)[1]))
     assert m.Pos == pos + 1
+    # the blocking calls are one hipGraph each (token in, kernels, candidates out), re-captured when (temperature, k) change; a model
+    # without graphs takes the eager form of the same sequence: identical candidates, step by step, also across a change of k
+    e = LlamaModel(mgr, synth.make_metadata(dims), w, 32, graph=False)
+    m.Reset()
+    t2 = 9
+    for step, (temp, k) in enumerate([(0.5, 40), (0.5, 40), (0.8, 8), (0.8, 8), (0.5, 40), (1.0, 64)]):
+        gi, gp = m.StepTopK(t2, temp, k)
+        ei, ep = e.StepTopK(t2, temp, k)
+        np.testing.assert_array_equal(gi, ei)
+        np.testing.assert_array_equal(gp, ep)
+        lg, am = m.Step(int(gi[0]))                      # the plain blocking step (its own graph) in between
+        le, ae = e.Step(int(gi[0]))
+        assert am == ae and np.array_equal(lg, le) and m.Pos == e.Pos == 2 * step + 2
+        t2 = am
+    e.Dispose()
     m.Dispose()
 
 
