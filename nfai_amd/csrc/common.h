@@ -201,6 +201,9 @@ hipError_t launch_f32_to_f16(const float *x, void *y_f16, uint64_t n, hipStream_
 hipError_t launch_sum_slabs(const float *slabs, uint32_t ks, uint64_t n, const float *R, float *C, hipStream_t s);  // C = R + sum of ks slabs of n floats
 hipError_t launch_read_ahead(const void *w, uint64_t bytes, uint32_t n_cu, hipStream_t s);  // side-stream hint: the next GEMM's weights -> Infinity Cache
 hipError_t launch_rmsnorm_rows(const float *x, const float *g, void *y_f16, uint32_t T, uint32_t E, float eps, hipStream_t s);
+// x_out = R + slab 0 + ... + slab ks-1 (slabs of T * E floats; the order of launch_sum_slabs), y = RMSNorm(x_out) * g as fp16: combine + norm in one pass
+hipError_t launch_rmsnorm_rows_combine(const float *slabs, uint32_t ks, const float *R, float *x_out, const float *g, void *y_f16, uint32_t T, uint32_t E, float eps,
+                                       hipStream_t s);
 hipError_t launch_rope_store_rows(const float *q, const float *k, const float *v, void *qh_f16, void *kc, void *vc, int kv_f16,
                                   uint64_t pos_stride, uint64_t head_stride, const float *freqs, uint32_t rope_dims, uint32_t H,
                                   uint32_t Hkv, uint32_t D, uint32_t pos0, uint32_t T, uint32_t ld, void *kh_f16, void *vt_f16,

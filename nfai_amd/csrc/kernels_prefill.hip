@@ -977,6 +977,10 @@ static hipError_t gemm_pick(GemmParams &p, uint32_t batch, uint32_t n_cu, int va
     // (four waves of 16 x 64, four stages of 16 KB).  NFAI_GEMM_M64_SHORT=0: the 128-row tiles at every row count.
     static const bool m64_short = !(getenv("NFAI_GEMM_M64_SHORT") && atoi(getenv("NFAI_GEMM_M64_SHORT")) == 0);
     if (m64_short && p.M <= 64 && p.causal == 0 && p.ksplit == 1) return gemm_launch_glds<64, 64, 4, 1, EPI, 4>(p, batch, s);
+    // A dense product whose K range the caller split over the batch dimension (llama.hip: Wdown at >= 256 rows): 256 x 128 tiles — per
+    // workgroup half the operand bytes of the 128 x 48 tiling this shape takes unsplit.
+    if (batch > 1 && p.causal == 0 && p.ksplit == 1 && p.M >= 256 && p.N % 128 == 0 && ((p.M + 127) / 128) % 2 == 0)
+        return gemm_launch_glds<256, 128, 4, 2, EPI, 3, 64, true>(p, batch, s);
     static const int env_big = getenv("NFAI_GEMM_BIG") ? atoi(getenv("NFAI_GEMM_BIG")) : 1;
     const uint64_t big_tiles = (uint64_t)((p.M + 127) / 128) * (p.N / 128) * batch;
     if constexpr (EPI == EPI_F32) {
@@ -1229,6 +1233,56 @@ __global__ __launch_bounds__(256) void k_rmsnorm_rows_v(const float *x, const fl
             *reinterpret_cast<f16x4 *>(yr + k) = o;
         }
     }
+}
+
+// The same behind a projection whose K range was split (llama.hip, Wdown at >= 256 rows): the row is residual + slab 0 + slab 1 + ...
+// (the order of k_sum_slabs: bit-identical to the two separate launches), written out as the fp32 residual stream AND normalised.
+template <int NV>
+__global__ __launch_bounds__(256) void k_rmsnorm_rows_combine(const float *slabs, uint32_t ks, uint64_t slab_stride, const float *R, float *xo, const float *g,
+                                                              _Float16 *y, uint32_t E, float eps)
+{
+    __shared__ float red[16];
+    const uint64_t row = (uint64_t)blockIdx.x * E;
+    const GLOBAL_AS float *gr = (const GLOBAL_AS float *)g;
+    f32x4 v[NV], gv[NV];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const uint32_t k = (threadIdx.x + i * 256) * 4, kk = min(k, E - 4);
+        f32x4 a = *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)R + row + kk);
+        gv[i] = *reinterpret_cast<const GLOBAL_AS f32x4 *>(gr + kk);
+        for (uint32_t z = 0; z < ks; z++) a += *reinterpret_cast<const GLOBAL_AS f32x4 *>((const GLOBAL_AS float *)slabs + z * slab_stride + row + kk);
+        v[i] = k < E ? a : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (k < E) *reinterpret_cast<f32x4 *>(xo + row + k) = a;
+#pragma unroll
+        for (int e = 0; e < 4; e++) ss = fmaf(v[i][e], v[i][e], ss);
+    }
+    ss = block_sum(ss, red);
+    const float rms = sqrtf(ss / (float)E + eps);
+    _Float16 *yr = y + row;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const uint32_t k = (threadIdx.x + i * 256) * 4;
+        if (k < E) {
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = (_Float16)((v[i][e] / rms) * gv[i][e]);
+            *reinterpret_cast<f16x4 *>(yr + k) = o;
+        }
+    }
+}
+
+hipError_t launch_rmsnorm_rows_combine(const float *slabs, uint32_t ks, const float *R, float *x_out, const float *g, void *y_f16, uint32_t T, uint32_t E, float eps,
+                                       hipStream_t s)
+{
+    _Float16 *y = static_cast<_Float16 *>(y_f16);
+    if (E % 4 || E < 4 || E > 4096 || ks == 0 || !R) return hipErrorInvalidValue;
+    const uint64_t stride = (uint64_t)T * E;
+    if (E <= 1024) k_rmsnorm_rows_combine<1><<<T, 256, 0, s>>>(slabs, ks, stride, R, x_out, g, y, E, eps);
+    else if (E <= 2048) k_rmsnorm_rows_combine<2><<<T, 256, 0, s>>>(slabs, ks, stride, R, x_out, g, y, E, eps);
+    else if (E <= 3072) k_rmsnorm_rows_combine<3><<<T, 256, 0, s>>>(slabs, ks, stride, R, x_out, g, y, E, eps);
+    else k_rmsnorm_rows_combine<4><<<T, 256, 0, s>>>(slabs, ks, stride, R, x_out, g, y, E, eps);
+    return hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void k_rmsnorm_rows(const float *x, const float *g, _Float16 *y, uint32_t E, float eps)

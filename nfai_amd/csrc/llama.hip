@@ -1151,8 +1151,13 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
     // One projection: up to three weight tensors side by side in the output columns.  Runs of tensors with the same
     // encoding share a launch (fp16: k_gemm_f16*, T16 K-quants: the dequant-in-LDS k_gemm_kq); a Q4_K_M q|k|v with a
     // Q6_K attn_v is two launches writing two column blocks of the same [T][ldc] buffer.
+    // A projection whose K range was split (long chunks, below) may leave its slabs in w.SC for the NEXT block's attention norm to add
+    // up (combine + RMSNorm in one pass): pend_ks > 0 until that launch, or the plain combine after the last block, has consumed them.
+    uint32_t pend_ks = 0;
+    const float *pend_R = nullptr;
+    const bool fuse_combine = !(getenv("NFAI_PREFILL_COMBINE_FUSED") && atoi(getenv("NFAI_PREFILL_COMBINE_FUSED")) == 0);   // read per call (a test flips it)
     auto gemm = [&](const void *A, uint32_t lda, const Tensor &W, const Tensor *W1, const Tensor *W2, float *C, const float *R, uint32_t N,
-                    uint32_t K) -> hipError_t {
+                    uint32_t K, bool may_defer = false) -> hipError_t {
         const Tensor *seg[3] = {&W, W1, W2};
         const int nseg = W2 ? 3 : (W1 ? 2 : 1);
         uint32_t col = 0;
@@ -1193,6 +1198,25 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
                     first = last + 1;
                     continue;
                 }
+            }
+            // Long chunks (>= 256 rows), K >= 8192 (Wdown): four K quarters on 256 x 128 tiles + the ordered combine (tools/gemm_bench.py
+            // splitk4-proxy: 37.1 against 47.4 us at 3B before the combine).  NFAI_PREFILL_SPLITK_LONG=0 switches it off.
+            static const bool split_long = !(getenv("NFAI_PREFILL_SPLITK_LONG") && atoi(getenv("NFAI_PREFILL_SPLITK_LONG")) == 0);
+            if (split_long && seg[first]->type == NFAI_F16 && nseg == 1 && T >= 256 && ((T + 127) / 128) % 2 == 0 && K >= 8192 && K % 256 == 0 && g.N % 128 == 0 &&
+                C != nullptr && (uint64_t)4 * T * g.N <= (uint64_t)d.H * w.T * w.Spad) {
+                GemmArgs gs = g;
+                gs.batch = 4; gs.K = K / 4; gs.a_bs = K / 4; gs.b_bs = K / 4; gs.c_bs = (uint64_t)T * g.N;
+                gs.C = w.SC; gs.R = nullptr;
+                if ((e = launch_gemm_f16(gs, s)) != hipSuccess) return e;
+                if (may_defer && fuse_combine && g.R && d.E % 4 == 0 && d.E <= 4096 && g.N == d.E) {
+                    pend_ks = 4;          // the next attention norm (or the tail of the chunk) adds residual + slabs into C = w.X
+                    pend_R = g.R;
+                } else if ((e = launch_sum_slabs(w.SC, 4, (uint64_t)T * g.N, g.R, static_cast<float *>(g.C), s)) != hipSuccess) {
+                    return e;
+                }
+                col += g.N;
+                first = last + 1;
+                continue;
             }
             if (seg[first]->type == NFAI_F16) {
                 e = launch_gemm_f16(g, s);
@@ -1269,7 +1293,12 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
             }
             if (w.wf16_all) w.wf16_done[li] = 1;
         }
-        P_TRY(launch_rmsnorm_rows(w.X, static_cast<const float *>(L.attn_norm.ptr), w.XN, T, d.E, d.eps, s));
+        if (pend_ks) {   // the previous block's Wdown left residual + K-split slabs: combine -> w.X and normalise in one pass
+            P_TRY(launch_rmsnorm_rows_combine(w.SC, pend_ks, pend_R, w.X, static_cast<const float *>(L.attn_norm.ptr), w.XN, T, d.E, d.eps, s));
+            pend_ks = 0;
+        } else {
+            P_TRY(launch_rmsnorm_rows(w.X, static_cast<const float *>(L.attn_norm.ptr), w.XN, T, d.E, d.eps, s));
+        }
         S_TRY(ahead({&L.wo}));                                                           // while q | k | v computes
         if (rope_fused_ok && L.wq.type == NFAI_F16 && L.wk.type == NFAI_F16 && L.wv.type == NFAI_F16) {
             GemmArgs g;                                                                  // q | k | v + RoPE + q / cache stores in one launch
@@ -1336,7 +1365,11 @@ static int prefill_chunk(Model *m, const uint32_t *tokens, uint32_t T)
             const Layer &N = *(&Lq + 1);
             S_TRY(ahead({&N.wq, &N.wk, &N.wv}));
         }
-        P_TRY(gemm(w.ACT, d.F, L.wdown, nullptr, nullptr, w.X, w.H1, d.E, d.F));           // + residual (:176-181)
+        P_TRY(gemm(w.ACT, d.F, L.wdown, nullptr, nullptr, w.X, w.H1, d.E, d.F, true));     // + residual (:176-181)
+    }
+    if (pend_ks) {   // the last block of the stage: nobody normalises behind it
+        P_TRY(launch_sum_slabs(w.SC, pend_ks, (uint64_t)T * d.E, pend_R, w.X, s));
+        pend_ks = 0;
     }
     if (ra_used) {  // the side stream only reads weights; the join keeps destroy / set_tensor from racing with it
         if (ra_ev >= m->pf_events.size()) {

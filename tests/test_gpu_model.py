@@ -512,6 +512,35 @@ def test_prefill_full_width_block(mgr, dims, chunk):
     m.Dispose()
 
 
+def test_prefill_long_chunk_k_split_and_fused_combine(mgr, monkeypatch):
+    """Chunks of >= 256 rows run Wdown (K >= 8192) as four K quarters on 256 x 128 tiles; the slabs are added up — residual + slab 0 + ... in
+    order — either by k_sum_slabs or, fused, by the next block's attention norm (k_rmsnorm_rows_combine): the two must be bit-identical
+    (NFAI_PREFILL_COMBINE_FUSED is read per call), over two blocks at the 3B widths (so that one combine is fused into a norm and the last
+    one is the plain tail), and the logits must agree with the oracle's token-by-token path within the prefill tolerance."""
+    from dataclasses import replace
+    from nfai_amd.llama_model import LlamaModel
+    d2 = replace(synth.LLAMA_32_3B, L=2, V=2048, name="llama-3.2-3b-2blk")
+    w = synth.make_weights(d2, seed=35)
+    n, C = 256, 272
+    toks = synth.make_tokens(d2, n, seed=16)
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("NFAI_PREFILL_COMBINE_FUSED", fused)
+        m = LlamaModel(mgr, synth.make_metadata(d2), w, C, max_batch=n)
+        lg = m.Prefill(toks)
+        outs.append((lg, m.Read(0, d2.E), [m.ReadKV(1, v, p) for v in (False, True) for p in (0, 100, n - 1)]))
+        m.Dispose()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert np.array_equal(a, b)
+    ref = orc.OracleLlama(odesc(d2, C), w)
+    for t in toks[:-1]:
+        ref.step(int(t), want_logits=False)
+    want = ref.step(int(toks[-1]))
+    assert np.abs(outs[0][0] - want).max() <= 2e-2 * max(1.0, float(np.abs(want).max()))
+    assert int(np.argmax(outs[0][0])) == orc.argmax(want)
+
+
 @pytest.mark.parametrize("dims,n,chunk,kv16", [(synth.TINY_D128, 130, 128, False), (synth.TINY_D128, 101, 64, True), (synth.TINY, 37, 64, False)],
                          ids=["d128-130", "d128-101-kvf16-unaligned-chunks", "tiny-d64"])
 def test_prefill_rope_in_the_gemm_epilogue_is_bit_identical(mgr, dims, n, chunk, kv16, monkeypatch):
