@@ -236,11 +236,6 @@ struct AttnArgs {
     uint32_t tag_mul = 1, tag_add = 0;
     uint32_t *err = nullptr;
     uint32_t debug_withhold = 0;  // test hook: slice (value - 1) of kv head 0 publishes nothing, so the others' bounded waits give up
-    // heralds (kernels_attn.hip): the workgroups without a slice request the first bytes of these ranges — the weights of the launches
-    // that follow, in the order they are streamed; ranges 1 and 2 are read side by side (gate | up) — pf_kb KiB per workgroup, and drop them
-    const void *pf_ptr[4] = {nullptr, nullptr, nullptr, nullptr};
-    uint64_t pf_bytes[4] = {0, 0, 0, 0};
-    uint32_t pf_kb = 0;
 };
 constexpr uint32_t ATTN_NSPLIT_MAX = 32;
 size_t attn_partials_bytes(uint32_t H, uint32_t Hkv, uint32_t D, bool granules = false);  // granules: the {value, tag} form (AttnArgs::epoch set)

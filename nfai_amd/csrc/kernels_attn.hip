@@ -61,10 +61,6 @@ struct AttnParams {
     uint32_t wo_lds_off;     // byte offset of the Wo waves' LDS region (after the attention waves')
     uint32_t wo_delay;       // x 64 clocks between launch start and the Wo waves' weight requests (workgroups that run a slice)
     uint32_t withhold;       // test hook (AttnArgs::debug_withhold)
-    // heralds (AttnArgs::pf_*): workgroups without a slice request the head of the following launches' weights and drop the bytes
-    const uint8_t *pf_ptr[4];
-    uint32_t pf_pieces[4];   // 4 KiB pieces of each range that may be requested
-    uint32_t pf_budget;      // pieces per herald workgroup (0: no heralds)
     NFAI_STAMP_PARAM
 };
 
@@ -130,39 +126,6 @@ __device__ __forceinline__ void publish(uint64_t *g, uint32_t tag, float v)
     // no fence and no flag — the reader polls the data itself)
     __hip_atomic_store((__attribute__((address_space(1))) uint64_t *)g, ((uint64_t)tag << 32) | (uint64_t)__builtin_bit_cast(uint32_t, v),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// ---- heralds ----------------------------------------------------------------------------------------------------------------
-// A decode attention launch is bound by latencies (K / V rows, slice hand-off, merge), not by bytes: at positions 520-650 it moves
-// 5-23 MB in 7-12 us while HBM could move 45-75, and the workgroups behind the last slice (split >= nsplit: 11-15 of 32 per kv head
-// at those positions) end at once.  Those workgroups — on CUs of their own, so nothing of theirs queues in front of a slice's
-// requests — instead read the first bytes of the weights the NEXT launches stream (Wo, gate | up, Wdown) and drop them: the lines
-// stay in the 256 MiB Infinity Cache (default policy; `tools/mall_bench.hip`: a 100 MB nt stream whose bytes were read just before
-// takes 14.8 instead of 18.8 us), and the GEMV launches, whose workgroups take their units in ascending order, start on cached
-// bytes.  Herald h of n takes pieces h, h + n, h + 2n, ... of the ranges' concatenation (ranges 1 and 2 — gate and up, read side by
-// side by one launch — alternate piece by piece), `budget` pieces each; a piece is 4 KiB, 16 bytes per lane.  Results are not
-// touched by any of this: the bytes are dropped.
-__device__ __forceinline__ void herald_run(const AttnParams &p, const uint32_t h, const uint32_t n, const uint32_t tid)
-{
-    const uint32_t n0 = p.pf_pieces[0], n12 = p.pf_pieces[1] + p.pf_pieces[2], n3 = p.pf_pieces[3];
-    const uint32_t total = n0 + n12 + n3;
-    // every load lands in the SAME four registers, which stay allocated to `drop` from the first request to the final wait ("+v": hipcc
-    // does not know that an inline-asm load completes later, and would hand the registers of a dead result to the next address)
-    u32x4 drop = {0, 0, 0, 0};
-    const uint8_t *b0 = p.pf_ptr[0], *b1 = p.pf_ptr[1], *b2 = p.pf_ptr[2], *b3 = p.pf_ptr[3];   // (in scalar registers for the whole loop)
-    const bool pair = p.pf_pieces[2] != 0;
-    for (uint32_t j = 0; j < p.pf_budget; j++) {
-        const uint32_t k = __builtin_amdgcn_readfirstlane(h + j * n);
-        if (k >= total) break;
-        const uint8_t *src;
-        if (k < n0) src = b0 + (uint64_t)k * 4096;
-        else if (k < n0 + n12) {
-            const uint32_t v = k - n0;   // pf_pieces[1] == pf_pieces[2] or the latter is 0 (fill_params)
-            src = pair ? ((v & 1) ? b2 : b1) + (uint64_t)(v >> 1) * 4096 : b1 + (uint64_t)v * 4096;
-        } else src = b3 + (uint64_t)(k - n0 - n12) * 4096;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(drop) : "v"(src + tid * 16) : "memory");
-    }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(drop) : : "memory");
 }
 
 // The attention waves' program.  PUB: the merged output is also published as {value, tag} granules (p.att_gran) for the Wo waves of
@@ -585,11 +548,6 @@ __device__ __forceinline__ void attn_body(const AttnParams &p, const uint32_t kv
 template <int LPP, int G, bool F16, bool ONLINE, bool POLL>
 __global__ __launch_bounds__(ATTN_BLOCK) void k_attn_decode(const AttnParams p)
 {
-    if (p.pf_budget) {
-        uint32_t nsplit, chunk;
-        attn_split(p.pos[0] + 1, p.min_chunk, p.max_split, nsplit, chunk);
-        if (blockIdx.y >= nsplit) { herald_run(p, (blockIdx.y - nsplit) * gridDim.x + blockIdx.x, (gridDim.y - nsplit) * gridDim.x, threadIdx.x); return; }
-    }
     attn_body<LPP, G, F16, ONLINE, POLL, false>(p, blockIdx.x, blockIdx.y);
 }
 
@@ -615,16 +573,6 @@ __global__ __launch_bounds__(ATTN_BLOCK + WO_WAVES * 64) void k_attn_wo(const At
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t kvh = blockIdx.x % p.Hkv, split = blockIdx.x / p.Hkv;
     if (wave < ATTN_BLOCK / 64) {
-        if (p.pf_budget) {
-            uint32_t nsplit, chunk;
-            attn_split(p.pos[0] + 1, p.min_chunk, p.max_split, nsplit, chunk);
-            const uint32_t first = nsplit * p.Hkv;   // workgroups first ... gridDim.x - 1 run no slice
-            if (blockIdx.x >= first) {
-                __builtin_amdgcn_s_barrier();   // the one barrier this workgroup's Wo waves execute (behind their weight requests)
-                herald_run(p, blockIdx.x - first, gridDim.x - first, threadIdx.x);
-                return;
-            }
-        }
         if (split < p.max_split) attn_body<LPP, G, F16, false, true, true>(p, kvh, split);
         return;
     }
@@ -836,13 +784,6 @@ static hipError_t fill_params(const AttnArgs &a, AttnParams &p, dim3 &grid, size
     // occupancy query says they are not (a partition with few CUs) the ticket form, which never waits, is used
     p.epoch = env_poll ? a.epoch : nullptr;  // (launch_g checks that the whole grid can be resident)
     p.tag_mul = a.tag_mul; p.tag_add = a.tag_add; p.err = a.err; p.withhold = a.debug_withhold;
-    for (int i = 0; i < 4; i++) {
-        p.pf_ptr[i] = static_cast<const uint8_t *>(a.pf_ptr[i]);
-        p.pf_pieces[i] = a.pf_ptr[i] ? (uint32_t)std::min<uint64_t>(a.pf_bytes[i] / 4096, 1u << 20) : 0;
-    }
-    if (p.pf_pieces[1] && p.pf_pieces[2]) p.pf_pieces[1] = p.pf_pieces[2] = std::min(p.pf_pieces[1], p.pf_pieces[2]);
-    else if (p.pf_pieces[2]) { p.pf_ptr[1] = p.pf_ptr[2]; p.pf_pieces[1] = p.pf_pieces[2]; p.pf_pieces[2] = 0; }
-    p.pf_budget = (p.pf_pieces[0] | p.pf_pieces[1] | p.pf_pieces[3]) ? a.pf_kb / 4 : 0;
     static const int env_mc = getenv("NFAI_ATTN_MIN_CHUNK") ? atoi(getenv("NFAI_ATTN_MIN_CHUNK")) : 0;
     static const int env_ms = getenv("NFAI_ATTN_MAX_SPLIT") ? atoi(getenv("NFAI_ATTN_MAX_SPLIT")) : 0;
     p.min_chunk = env_mc >= 4 ? (uint32_t)env_mc : ATTN_MIN_CHUNK;

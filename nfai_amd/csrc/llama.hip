@@ -49,8 +49,6 @@ struct Model {
     bool first_stage = false, last_stage = false;
     bool unfused = false, use_graph = true, kv_f16 = false;
     bool engine = false;             // requested: one engine launch per block where the tensors allow it
-    uint32_t herald_kb = 0;          // KiB of the following launches' weights each slice-less attention workgroup requests ahead (kernels_attn.hip, heralds)
-    bool herald_down = true;         // ... Wdown included
     bool attn_ticket = false;        // a bounded wait of the granule hand-off gave up once: this model stays on the ticket form, which never waits
     uint32_t dbg_withhold = 0;       // test hook (nfai_hip_debug_attn_withhold)
     uint64_t *d_gran = nullptr;      // engine hand-off granules: per block h (E) | act (F) | x (E)
@@ -396,16 +394,8 @@ int block_fused(Model *m, Layer &L, Sched &sch, const GemvArgs::Begin *begin = n
     {
         GemvArgs a = gemv_base(m, L.wo, m->att, d.H * d.D);
         a.mode = GEMV_RESIDUAL; a.res = m->x; a.y = m->h;
-        AttnArgs at = attn_args(m, L);
-        const bool wo_fused = attn_wo_ok(at, a);
-        if (m->herald_kb) {   // the launches behind the attention, in order: [Wo], gate | up, Wdown
-            if (!wo_fused) { at.pf_ptr[0] = L.wo.ptr; at.pf_bytes[0] = L.wo.bytes; }
-            at.pf_ptr[1] = L.wgate.ptr; at.pf_bytes[1] = L.wgate.bytes;
-            at.pf_ptr[2] = L.wup.ptr; at.pf_bytes[2] = L.wup.bytes;
-            if (m->herald_down) { at.pf_ptr[3] = L.wdown.ptr; at.pf_bytes[3] = L.wdown.bytes; }
-            at.pf_kb = m->herald_kb;
-        }
-        if (wo_fused) {  // attention + Wo + residual in one launch (fp16 Wo, the shapes of kernels_attn.hip's table)
+        const AttnArgs at = attn_args(m, L);
+        if (attn_wo_ok(at, a)) {  // attention + Wo + residual in one launch (fp16 Wo, the shapes of kernels_attn.hip's table)
             S_TRY(sch.submit(op_fn(KC_ATTN, [at, a](hipStream_t st) { return launch_attn_wo(at, a, st); })));
         } else {
             S_TRY(sch.submit(op_attn(KC_ATTN, at)));
@@ -706,12 +696,6 @@ NFAI_API int32_t nfai_hip_llama_create(nfai_ctx_t ch, const nfai_llama_desc *des
     {
         const char *env = getenv("NFAI_ENGINE");
         m->engine = !m->unfused && (env ? (env[0] == '1') : ((d.flags & NFAI_LLAMA_ENGINE) != 0));
-    }
-    {
-        const char *env = getenv("NFAI_HERALD_KB"), *dn = getenv("NFAI_HERALD_DOWN");
-        const int kb = env ? atoi(env) : 0;
-        m->herald_kb = kb > 0 ? (uint32_t)std::min(kb, 4096) : 0;
-        m->herald_down = !(dn && atoi(dn) == 0);
     }
     if (m->unfused && m->kv_f16) { delete m; return fail(NFAI_ERR_INVALID, "llama_create: the 1:1 chain keeps the reference's fp32 KV cache"); }
     m->layers.resize(d.layer_end - d.layer_begin);
