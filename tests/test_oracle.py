@@ -226,3 +226,51 @@ def test_topp_from_candidates_vectorised_equals_the_loop_and_the_oracle():
             a = SamplingUtils.TopPFromCandidates(ids, probs, 0.95, rand=rand)
             b = SamplingUtils.TopPFromCandidatesLoop(ids, probs, 0.95, rand=rand)
             assert a == b == want, (trial, rand, a, b, want)
+
+
+@pytest.mark.parametrize("dims", [synth.TINY, synth.TINY_D128], ids=lambda d: d.name)
+def test_whole_model_vs_hf_transformers_llama(dims):
+    """An implementation of the architecture that shares no code with this repository or with the reference: Hugging Face
+    transformers' LlamaForCausalLM (fp32, eager attention, CPU) on the same synthetic weights.  GGUF files store Wq / Wk with the rows
+    of a head permuted so that the rotation of NEIGHBOURING pairs (2i, 2i+1) — what RoPEShader.cs:238-271 and ggml do — equals
+    transformers' rotate-half convention (i, i + D/2) on the original rows; the inverse permutation is applied here.  Every position's
+    logits of one causal forward pass must equal the oracle's token-by-token logits (LlamaModel.cs:116-125) to fp32 summation noise.
+    This does not pin the oracle to the REFERENCE (which holds no vectors: parity stays "unpinned") — it pins it to the
+    model the reference implements: RMSNorm, GQA head mapping, 1/sqrt(D), the causal softmax, up * silu(gate), tied / untied lm_head."""
+    torch = pytest.importorskip("torch")
+    tf = pytest.importorskip("transformers")
+    d = dims
+    w = synth.make_weights(d, seed=5, std=0.05)
+    cfg = tf.LlamaConfig(vocab_size=d.V, hidden_size=d.E, intermediate_size=d.F, num_hidden_layers=d.L, num_attention_heads=d.H,
+                         num_key_value_heads=d.Hkv, head_dim=d.D, rms_norm_eps=1e-5, rope_theta=500000.0, tie_word_embeddings=d.tied,
+                         attention_bias=False, mlp_bias=False, max_position_embeddings=64, attn_implementation="eager")
+    hf = tf.LlamaForCausalLM(cfg).to(torch.float32).eval()
+
+    def rotate_half_rows(wg, n_heads):  # GGUF row order (pairs interleaved) -> transformers' (first halves, then second halves)
+        wg = wg.astype(np.float32).reshape(n_heads, d.D // 2, 2, -1)
+        return np.concatenate([wg[:, :, 0, :], wg[:, :, 1, :]], axis=1).reshape(n_heads * d.D, -1)
+
+    f32 = lambda a: a.astype(np.float32)  # noqa: E731
+    sd = {"model.embed_tokens.weight": f32(w["token_embd.weight"]), "model.norm.weight": w["output_norm.weight"],
+          "lm_head.weight": f32(w["token_embd.weight"] if d.tied else w["output.weight"])}
+    for l in range(d.L):
+        b, h = f"blk.{l}.", f"model.layers.{l}."
+        sd[h + "input_layernorm.weight"] = w[b + "attn_norm.weight"]
+        sd[h + "post_attention_layernorm.weight"] = w[b + "ffn_norm.weight"]
+        sd[h + "self_attn.q_proj.weight"] = rotate_half_rows(w[b + "attn_q.weight"], d.H)
+        sd[h + "self_attn.k_proj.weight"] = rotate_half_rows(w[b + "attn_k.weight"], d.Hkv)
+        sd[h + "self_attn.v_proj.weight"] = f32(w[b + "attn_v.weight"])
+        sd[h + "self_attn.o_proj.weight"] = f32(w[b + "attn_output.weight"])
+        sd[h + "mlp.gate_proj.weight"] = f32(w[b + "ffn_gate.weight"])
+        sd[h + "mlp.up_proj.weight"] = f32(w[b + "ffn_up.weight"])
+        sd[h + "mlp.down_proj.weight"] = f32(w[b + "ffn_down.weight"])
+    res = hf.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, strict=False)
+    assert not res.missing_keys and not res.unexpected_keys, res
+    toks = synth.make_tokens(d, 24, seed=3)
+    with torch.no_grad():
+        want = hf(torch.from_numpy(toks.astype(np.int64))[None]).logits[0].numpy()
+    ref = orc.OracleLlama(orc.LlamaDesc(E=d.E, L=d.L, H=d.H, Hkv=d.Hkv, D=d.D, F=d.F, V=d.V, C=32), w)
+    for i, t in enumerate(toks):
+        got = ref.step(int(t))
+        assert np.abs(got - want[i]).max() <= 1e-4 * max(1.0, float(np.abs(want[i]).max())), i   # observed 1.2e-5 at |logit| <= 5.5
+        assert int(np.argmax(got)) == int(np.argmax(want[i])), i
