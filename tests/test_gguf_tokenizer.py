@@ -150,3 +150,38 @@ def test_detokenize():
     out = tok.Tokenize("hello, world!", True)
     text = tok.Detokenize(out)
     assert "hello, world!" in text and text.startswith("<|begin_of_text|>")
+
+
+def test_bpe_and_pretokenizer_against_the_tokenizers_library():
+    """The merge loop (lowest rank first, leftmost on ties; Tokenizer.cs:130-166) and the Llama-3 split pattern (Tokenizer.cs:93-111)
+    against an implementation that shares no code with this repository or the reference: the `tokenizers` library's byte-level BPE with
+    the same split pattern, on a vocabulary and merge list trained by that library from a small corpus (nothing is downloaded).  Printable
+    ASCII, spaces and newlines only: for those the reference's initial units (' ' -> 'Ġ', '\\n' -> 'Ċ', every other character itself;
+    Tokenizer.cs:242-267) coincide with the GPT-2 byte map — a tab or a non-ASCII character does not (kept as the reference has it, see
+    the module docstring), so those are outside this cross-check."""
+    import json
+    tk = pytest.importorskip("tokenizers")
+    from tokenizers import Regex, models, pre_tokenizers, trainers
+    from nfai_amd.tokenizer import Tokenizer, _PRETOK
+    corpus = ["The quick brown fox jumps over the lazy dog. " * 3, "def main():\n    print('hello, world')\n    return 0\n",
+              "It's 2024 and we've got 1234567 reasons; they're all fine!  Aren't they?\n\nYes -- they'll do.",
+              "tokenization of repeated tokens tokens tokens", "  leading spaces and   runs   of   spaces \n \n trailing "]
+    hf = tk.Tokenizer(models.BPE())
+    hf.pre_tokenizer = pre_tokenizers.Sequence([pre_tokenizers.Split(Regex(_PRETOK.pattern), behavior="isolated"),
+                                                pre_tokenizers.ByteLevel(add_prefix_space=False, use_regex=False)])
+    hf.train_from_iterator(corpus * 4, trainers.BpeTrainer(vocab_size=400, initial_alphabet=pre_tokenizers.ByteLevel.alphabet(),
+                                                           special_tokens=[], show_progress=False))
+    model = json.loads(hf.to_str())["model"]
+    toks = [None] * len(model["vocab"])
+    for t, i in model["vocab"].items():
+        toks[i] = t
+    merges = [m if isinstance(m, str) else " ".join(m) for m in model["merges"]]
+    assert len(merges) > 100
+    mine = Tokenizer({"tokenizer.ggml.tokens": toks, "tokenizer.ggml.merges": merges, "tokenizer.ggml.bos_token_id": 0,
+                      "tokenizer.ggml.eos_token_id": 0})
+    texts = corpus + ["Hello there, world!  What's   up?\nfine\n\n\nok 12 123 1234 12345", "a", " ", "", "x  y", "don't DON'T 'S 'Ll",
+                      "the the the then there other", "trailing newline\n", "\n\n\nleading newlines", "a.b,c;d:e!f?g(h)i[j]k{l}m"]
+    for t in texts:
+        got = [mine.byteSequenceToId[part] for piece in _PRETOK.finditer(t) for part in mine._bpe(mine.ToInitialBpeUnits(piece.group(0)))]
+        assert got == hf.encode(t).ids, t
+        assert mine.Detokenize(got) == t
