@@ -512,7 +512,8 @@ def test_prefill_full_width_block(mgr, dims, chunk):
     m.Dispose()
 
 
-def test_prefill_long_chunk_k_split_and_fused_combine(mgr, monkeypatch):
+@pytest.mark.parametrize("n", [256, 500], ids=["256-rows", "500-rows-ragged"])
+def test_prefill_long_chunk_k_split_and_fused_combine(mgr, monkeypatch, n):
     """Chunks of >= 256 rows run Wdown (K >= 8192) as four K quarters on 256 x 128 tiles; the slabs are added up — residual + slab 0 + ... in
     order — either by k_sum_slabs or, fused, by the next block's attention norm (k_rmsnorm_rows_combine): the two must be bit-identical
     (NFAI_PREFILL_COMBINE_FUSED is read per call), over two blocks at the 3B widths (so that one combine is fused into a norm and the last
@@ -521,7 +522,7 @@ def test_prefill_long_chunk_k_split_and_fused_combine(mgr, monkeypatch):
     from nfai_amd.llama_model import LlamaModel
     d2 = replace(synth.LLAMA_32_3B, L=2, V=2048, name="llama-3.2-3b-2blk")
     w = synth.make_weights(d2, seed=35)
-    n, C = 256, 272
+    C = n + 16   # (500 rows: four 128-row blocks, the last one ragged — rows past the chunk's end are neither stored nor added)
     toks = synth.make_tokens(d2, n, seed=16)
     outs = []
     for fused in ("1", "0"):
