@@ -301,11 +301,12 @@ def run_single(args):
         flops = dims.L * (per_layer + attn) + 2 * dims.V * dims.E
         mfma_util = None
         try:   # MFMA-busy counters of these GEMMs (separate rocprofv3 --pmc passes, tools/prefill_pmc.py), collected offline on this build
-            pm = json.load(open(os.path.join(ROOT, "profiles", "round4_prefill_pmc.json")))
+            pm_name = next(n for n in ("round4_prefill_pmc_final.json", "round4_prefill_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+            pm = json.load(open(os.path.join(ROOT, "profiles", pm_name)))
             mfma_util = {"value": pm.get("mfma_busy_frac"), "by_kernel": pm.get("mfma_busy_frac_by_kernel"),
-                         "source": "profiles/round4_prefill_pmc.json (tools/prefill_pmc.py: SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE per GEMM launch, "
+                         "source": f"profiles/{pm_name} (tools/prefill_pmc.py: SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x duration x 2.4 GHz) per GEMM launch, "
                                    "one rocprofv3 --pmc pass per counter group); collected offline on this build, NOT in this run"}
-        except (OSError, ValueError):
+        except (OSError, ValueError, StopIteration):
             pass
         prefill = {"tokens": T, "ms": pf_ms, "ms_runs": pf_runs, "ms_first_call": pf_first, "tokens_per_s": T / (pf_ms * 1e-3), "tflops": flops / (pf_ms * 1e-3) / 1e12,
                    "peak_tflops": 2500.0, "frac_of_mfma_peak": flops / (pf_ms * 1e-3) / 1e12 / 2500.0, "mfma_util": mfma_util,

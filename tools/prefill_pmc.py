@@ -66,7 +66,10 @@ def main():
             for row in csv.DictReader(open(kt[0])):
                 k = short(row["Kernel_Name"])
                 if k:
-                    agg[(k, row["Grid_Size_X"] if "Grid_Size_X" in row else row.get("Grid_Size"))]["_dur_us_%d" % gi].append(
+                    # (the counter file's Grid_Size is the launch's total thread count; a batched GEMM has a z dimension)
+                    gsz = (str(int(row["Grid_Size_X"]) * int(row.get("Grid_Size_Y", 1) or 1) * int(row.get("Grid_Size_Z", 1) or 1))
+                           if "Grid_Size_X" in row else row.get("Grid_Size"))
+                    agg[(k, gsz)]["_dur_us_%d" % gi].append(
                         (int(row["Dispatch_Id"]), (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3))
         subprocess.run(["rm", "-rf", d])  # raw traces: tens of MB (gpurun copies back at most 64 MiB)
     out = {"command": "rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python3 tools/prefill_prof.py   (one pass per group: "
