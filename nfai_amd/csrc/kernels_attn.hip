@@ -849,7 +849,10 @@ static bool attn_wo_plan(const AttnArgs &a, const GemvArgs &g, uint32_t &nbw, At
     // (A Q4_K Wo was built into this launch too — one 16-row tile per workgroup, the Wo waves staging their pieces of the attention
     //  output as fixed-point MFMA fragments after the hand-off — and measured at 3B Q4_K_M: 973 tokens/s against 1019 with the two
     //  launches.  The staging, integer dot products and cross-wave sum that follow the hand-off take as long as the whole separate
-    //  launch, whose stream is only 7 KB per CU; removed.)
+    //  launch, whose stream is only 7 KB per CU; removed.  Round 4 tried the form that stages nothing — every Wo wave polls only the
+    //  256 elements of its own super-block, fp32 sums of q x and of x per sub-block scaled as ggml dequantises, no meeting before the
+    //  products — parity-green, 12.6 us against 7.95 + 3.6 as two launches, 1083 -> 1045 tokens/s: the hand-off costs what the
+    //  launch boundary costs.  profiles/round4_attn_wo_q4_ab.txt)
     if (g.w_type != NFAI_F16 || HD % 512) return false;
     nbw = E / 4 < a.n_cu ? E / 4 : a.n_cu;
     if (nbw == 0) return false;
