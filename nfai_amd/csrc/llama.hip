@@ -714,12 +714,12 @@ NFAI_API int32_t nfai_hip_llama_create(nfai_ctx_t ch, const nfai_llama_desc *des
     }
     DALLOC(m->d_pos, 256);
     DALLOC(m->d_tok, 256);
+    m->d_engerr = m->d_tok + 1;   // the sticky error word sits next to the token word: ONE 8-byte copy takes both to the host after a blocking step
     DALLOC(m->d_ring, RING_LEN * 4);
     DALLOC(m->d_freqs, (d.D / 2 + 8) * 4);
     DALLOC(m->d_ropecs, (d.D + 16) * 4);
     DALLOC(m->d_argmax_part, 4096 + argmax_fused_bytes());  // k_argmax's partials | the fused lm_head + ArgMax launch's
     DALLOC(m->d_epoch, 256);
-    DALLOC(m->d_engerr, 256);
     if (m->engine) DALLOC(m->d_gran, (size_t)m->layers.size() * (2 * (size_t)d.E + d.F) * 8);
     DALLOC(m->d_attn_part, attn_partials_bytes(d.H, d.Hkv, d.D, true) + attn_wo_extra_bytes(d.H, d.D));
     DALLOC(m->x, d.E * 4);
@@ -809,7 +809,7 @@ NFAI_API int32_t nfai_hip_llama_destroy(nfai_model_t h)
         free_t(L.ffn_norm); free_t(L.wgate); free_t(L.wup); free_t(L.wdown);
         hipFree(L.kcache); hipFree(L.vcache);
     }
-    void *ptrs[] = {m->d_topk, m->d_engparams, m->d_gran, m->d_epoch, m->d_engerr, m->d_pos, m->d_tok, m->d_ring, m->d_freqs, m->d_ropecs, m->d_argmax_part, m->d_attn_part, m->x, m->h,
+    void *ptrs[] = {m->d_topk, m->d_engparams, m->d_gran, m->d_epoch, m->d_pos, m->d_tok, m->d_ring, m->d_freqs, m->d_ropecs, m->d_argmax_part, m->d_attn_part, m->x, m->h,
                     m->q, m->att, m->act, m->logits, m->xn, m->qraw, m->scores, m->wts, m->proj, m->gate, m->up};
     for (void *p : ptrs) if (p) hipFree(p);
     void *pfp[] = {m->pf.CS, m->pf.toks, m->pf.X, m->pf.H1, m->pf.Q, m->pf.K, m->pf.V, m->pf.ATT, m->pf.G, m->pf.U, m->pf.SC,
@@ -981,8 +981,7 @@ static int ensure_sync_graph(Model *m, Model::SyncGraph &sg, bool topk, float te
     hipError_t e = hipMemcpyAsync(m->d_tok, m->h_pin + 2, 4, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) rc = enqueue_token(m, true);
     if (e == hipSuccess && !rc && topk) e = launch_topk(m->logits, m->d.V, temperature, k, m->d_topk, s);
-    if (e == hipSuccess && !rc) e = hipMemcpyAsync(m->h_pin, m->d_tok, 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess && !rc) e = hipMemcpyAsync(m->h_pin + 1, m->d_engerr, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && !rc) e = hipMemcpyAsync(m->h_pin, m->d_tok, 8, hipMemcpyDeviceToHost, s);   // token word + error word (adjacent)
     if (e == hipSuccess && !rc && topk)
         e = hipMemcpyAsync(m->h_pin + 4, static_cast<const char *>(m->d_topk) + topk_out_offset(), sizeof(TopkOut), hipMemcpyDeviceToHost, s);
     hipGraph_t g = nullptr;
@@ -1028,8 +1027,7 @@ static int step_blocking(Model *m, uint32_t token, bool topk = false, float temp
                 if (e != hipSuccess) return fail(NFAI_ERR_HIP, "decode_topk: launch failed: %s", hipGetErrorString(e));
                 HIP_TRY(hipMemcpyAsync(m->h_pin + 4, static_cast<const char *>(m->d_topk) + topk_out_offset(), sizeof(TopkOut), hipMemcpyDeviceToHost, s));
             }
-            HIP_TRY(hipMemcpyAsync(m->h_pin, m->d_tok, 4, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipMemcpyAsync(m->h_pin + 1, m->d_engerr, 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(m->h_pin, m->d_tok, 8, hipMemcpyDeviceToHost, s));   // token word + error word (adjacent)
         }
         HIP_TRY(hipStreamSynchronize(s));
         const uint32_t code = m->h_pin[1];
