@@ -416,7 +416,10 @@ def run_single(args):
                    "xcd_row_shares": dict(zip(("shares", "probe_us_equal_shares"), mgr.XcdShares()))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "frac_of_measured_ceiling": achieved / HBM_MEASURED_CEILING_GBPS,
-                     "measured_ceiling": HBM_MEASURED_CEILING_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                     "measured_ceiling": HBM_MEASURED_CEILING_GBPS,
+                     "measured_ceiling_note": "the MI355X guide's float4-copy figure (SURVEY 8d asks for the fraction of both); a long nt register stream "
+                                              "exceeds it here: the lm_head launch's fraction of it is above 1, and profiles/round2_ldsdma_bench.txt has 7.0 TB/s",
+                     "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": dom_name,
                      "bytes_per_launch": dom_bytes, "us_per_launch": gu_ms * 1e3, "us_per_launch_eager_event_pair": gu_eager_ms * 1e3,
                      "timing": "hipEvents on the launch stream around 4 rounds of the kernel's launches of one step (one per block), back to back",
